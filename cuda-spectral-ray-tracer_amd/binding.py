@@ -1,0 +1,129 @@
+"""ctypes binding of the C-ABI declared in include/srt_c_api.h (libsrt_hip.so).
+
+Nothing in here computes: it declares the structs / prototypes and turns negative status codes into
+exceptions.  There is no fallback path: if the shared library is missing, loading raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsrt_hip.so")
+
+N_CIE = 95
+TILE_PLANES = 9
+TILE_LANES = 64
+
+SCENE_CORNELL, SCENE_PRISM, SCENE_TRIS, SCENE_RANDOM_SPHERES, SCENE_MESH100K = 0, 1, 2, 100, 101
+BVH_REFERENCE, BVH_SAH = 0, 1
+MAT_LAMBERTIAN, MAT_METALLIC, MAT_DIELECTRIC, MAT_EMISSIVE, MAT_NO_MAT = 0, 1, 2, 4, 6
+
+
+class TriIn(C.Structure):
+    _fields_ = [("v0", C.c_float * 3), ("v1", C.c_float * 3), ("v2", C.c_float * 3),
+                ("mat_index", C.c_uint32), ("aa_plane", C.c_uint32)]
+
+
+class Material(C.Structure):
+    _fields_ = [("col", C.c_float * 3), ("reflection_fuzz", C.c_float), ("material_type", C.c_uint32),
+                ("spectral_distribution", C.c_float * N_CIE), ("emission_power", C.c_float),
+                ("sellmeier_B", C.c_float * 3), ("sellmeier_C", C.c_float * 3)]
+
+
+class CameraData(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32),
+                ("pixel_delta_u", C.c_float * 3), ("pixel_delta_v", C.c_float * 3), ("pixel00_loc", C.c_float * 3),
+                ("defocus_angle", C.c_float),
+                ("camera_center", C.c_float * 3), ("defocus_disk_u", C.c_float * 3), ("defocus_disk_v", C.c_float * 3)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("rays", C.c_uint64), ("paths", C.c_uint64), ("node_visits", C.c_uint64), ("tri_tests", C.c_uint64),
+                ("box_tests", C.c_uint64), ("reserved", C.c_uint64 * 3)]
+
+
+assert C.sizeof(Material) == 428 and C.sizeof(CameraData) == 84 and C.sizeof(TriIn) == 44
+
+# every symbol include/srt_c_api.h declares: name -> (restype, argtypes)
+_vp, _i, _u32, _u64, _f, _sz = C.c_void_p, C.c_int, C.c_uint32, C.c_uint64, C.c_float, C.c_size_t
+_fp = C.POINTER(C.c_float)
+PROTOTYPES = {
+    "srt_version": (C.c_char_p, []),
+    "srt_camera_init": (_i, [_i, _i, _f, _fp, _fp, _fp, _f, _f, C.POINTER(CameraData)]),
+    "srt_scene_create": (_vp, []),
+    "srt_scene_builtin": (_vp, [_i, _u64]),
+    "srt_scene_destroy": (None, [_vp]),
+    "srt_scene_default_camera": (_i, [_vp, _i, _i, C.POINTER(CameraData)]),
+    "srt_scene_set_triangles": (_i, [_vp, C.POINTER(TriIn), _sz]),
+    "srt_scene_set_materials": (_i, [_vp, C.POINTER(Material), _sz]),
+    "srt_scene_set_background": (_i, [_vp, _fp]),
+    "srt_scene_tri_count": (_sz, [_vp]),
+    "srt_scene_material_count": (_sz, [_vp]),
+    "srt_scene_get_triangles": (_i, [_vp, C.POINTER(TriIn)]),
+    "srt_scene_get_materials": (_i, [_vp, C.POINTER(Material)]),
+    "srt_scene_get_background": (_i, [_vp, _fp]),
+    "srt_scene_get_tri_records": (_i, [_vp, _fp]),
+    "srt_material_bake": (_i, [C.POINTER(Material)]),
+    "srt_bake_sigmoid_spectrum": (_i, [_fp, _f, _i, _fp]),
+    "srt_background_spectrum": (_i, [_fp, _fp]),
+    "srt_scene_build_bvh": (_i, [_vp, _i, _u64]),
+    "srt_scene_node_count": (_sz, [_vp]),
+    "srt_scene_bvh_depth": (_i, [_vp]),
+    "srt_scene_get_bvh": (_i, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), _fp]),
+    "srt_create": (_i, [_i, C.POINTER(_vp)]),
+    "srt_destroy": (None, [_vp]),
+    "srt_last_error": (C.c_char_p, [_vp]),
+    "srt_upload_scene": (_i, [_vp, _vp]),
+    "srt_set_camera": (_i, [_vp, C.POINTER(CameraData)]),
+    "srt_init_device_params": (_i, [_vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _u64]),
+    "srt_set_partition": (_i, [_vp, _u32, _u32]),
+    "srt_render_chunk": (_i, [_vp, _u32, _u32, _u32, _u32, _vp]),
+    "srt_synchronize": (_i, [_vp]),
+    "srt_tile_buffer": (_i, [_vp, C.POINTER(_vp), C.POINTER(_sz), C.POINTER(_u32), C.POINTER(_u32)]),
+    "srt_scatter_tiles": (_i, [_vp, _vp, _vp]),
+    "srt_dev_fb": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_sz)]),
+    "srt_read_fb": (_i, [_vp, _fp, _fp, _fp]),
+    "srt_read_fb_rowmajor": (_i, [_vp, _fp, _fp, _fp, _u32, _u32]),
+    "srt_read_fb_aux": (_i, [_vp, _i, _fp, _fp, _fp]),
+    "srt_get_stats": (_i, [_vp, C.POINTER(Stats)]),
+    "srt_set_count_traversal": (_i, [_vp, _i]),
+    "srt_last_kernel_ms": (_i, [_vp, C.POINTER(_f)]),
+    "srt_trace_rays": (_i, [_vp, _fp, _sz, _fp]),
+    "srt_device_op_sweep": (_i, [_vp, _i, _fp, _fp, _sz, _fp]),
+}
+
+
+class SrtError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("srt error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    """Load libsrt_hip.so (built in-tree by __graft_entry__.build()).  No fallback: raises if absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("%s not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(there is no CPU fallback for the render path)" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(L, name)          # AttributeError if the library does not export it
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(code, ctx=None):
+    if code is not None and code < 0:
+        msg = lib().srt_last_error(ctx)
+        raise SrtError(code, msg.decode() if msg else "")
+    return code
+
+
+def fptr(arr):
+    """float32 C-contiguous numpy array -> float*"""
+    return arr.ctypes.data_as(_fp)

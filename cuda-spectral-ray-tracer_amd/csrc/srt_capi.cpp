@@ -1,0 +1,370 @@
+// srt_capi.cpp -- device half of the C-ABI: one srt_ctx = one GPU's renderer
+// (replaces `renderer`, rendering/rendering.cuh:39-155, and the device half of render_manager::step).
+#include <hip/hip_runtime.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "srt_host.h"
+#include "srt_internal.h"
+
+using namespace srt;
+
+struct srt_ctx {
+    int device = 0;
+    std::string err;
+    // scene images in HBM
+    float *d_nodes = nullptr, *d_tris = nullptr, *d_mat_sd = nullptr, *d_mat_par = nullptr, *d_bg = nullptr, *d_cmf = nullptr;
+    int root_ref = 0, stack_depth = 1;
+    uint32_t n_materials = 0;
+    bool scene_ready = false, camera_ready = false, params_ready = false;
+    srt_camera_data cam;
+    // launch geometry (renderer::init_device_params)
+    uint32_t tx = 0, ty = 0, bx = 0, by = 0, chunk_w = 0, chunk_h = 0, spp = 0, bounce = 0;
+    uint64_t seed = SRT_DEFAULT_SEED;
+    uint32_t n_lanes = 0;
+    uint32_t rank = 0, world = 1;
+    // last chunk
+    uint32_t last_w = 0, last_h = 0, last_offx = 0, last_offy = 0;
+    uint32_t tiles_x = 0, tiles_y = 0, n_tiles = 0, tiles_local = 0, tiles_padded = 0;
+    // buffers
+    uint32_t *d_rng = nullptr;
+    float *d_fb = nullptr;          // 9 block-linear planes of n_lanes floats
+    float *d_tiles = nullptr;       // compact tile buffer
+    size_t tiles_capacity = 0;      // floats
+    unsigned long long *d_counters = nullptr;
+    bool count_traversal = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    uint64_t last_paths = 0;
+};
+
+namespace {
+
+int fail(srt_ctx *ctx, int code, const std::string &msg) {
+    if (ctx) ctx->err = msg;
+    set_global_error(msg);
+    return code;
+}
+int hip_fail(srt_ctx *ctx, hipError_t e, const char *what) {
+    return fail(ctx, SRT_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define HIP_TRY(ctx, expr)                                     \
+    do {                                                       \
+        hipError_t _e = (expr);                                \
+        if (_e != hipSuccess) return hip_fail(ctx, _e, #expr); \
+    } while (0)
+
+template <typename T>
+int upload(srt_ctx *ctx, T **dst, const std::vector<float> &src) {
+    if (*dst) { (void)hipFree(*dst); *dst = nullptr; }
+    HIP_TRY(ctx, hipMalloc((void **)dst, src.size() * sizeof(float)));
+    HIP_TRY(ctx, hipMemcpy(*dst, src.data(), src.size() * sizeof(float), hipMemcpyHostToDevice));
+    return SRT_OK;
+}
+
+void fill_params(const srt_ctx *c, RenderParams &p) {
+    memset(&p, 0, sizeof(p));
+    p.nodes = (const float4 *)c->d_nodes; p.tris = (const float4 *)c->d_tris;
+    p.mat_sd = (const float2 *)c->d_mat_sd; p.mat_par = (const float4 *)c->d_mat_par;
+    p.bg_sd = (const float2 *)c->d_bg; p.cmf = (const float4 *)c->d_cmf;
+    p.root_ref = c->root_ref; p.stack_depth = c->stack_depth; p.n_materials = c->n_materials;
+    for (int k = 0; k < 3; k++) {
+        p.du[k] = c->cam.pixel_delta_u[k]; p.dv[k] = c->cam.pixel_delta_v[k]; p.p00[k] = c->cam.pixel00_loc[k];
+        p.center[k] = c->cam.camera_center[k]; p.disk_u[k] = c->cam.defocus_disk_u[k]; p.disk_v[k] = c->cam.defocus_disk_v[k];
+    }
+    p.defocus_angle = c->cam.defocus_angle;
+    p.tx = c->tx; p.ty = c->ty; p.bx = c->bx; p.by = c->by;
+    p.spp = c->spp; p.bounce_limit = c->bounce;
+    p.rank = c->rank; p.world = c->world;
+    p.rng = c->d_rng; p.n_lanes = c->n_lanes;
+    p.tile_out = c->d_tiles; p.counters = c->d_counters;
+}
+
+}  // namespace
+
+extern "C" {
+
+int srt_create(int device, srt_ctx **out) {
+    if (!out) return fail(nullptr, SRT_ERR_INVALID, "srt_create: null out");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(nullptr, SRT_ERR_NO_DEVICE, std::string("srt_create: no HIP device (") + (e != hipSuccess ? hipGetErrorString(e) : "count 0") +
+                                                    "); this library has no CPU fallback");
+    if (device < 0 || device >= n) return fail(nullptr, SRT_ERR_NO_DEVICE, "srt_create: device index out of range");
+    e = hipSetDevice(device);
+    if (e != hipSuccess) return hip_fail(nullptr, e, "hipSetDevice");
+    srt_ctx *c = new srt_ctx();
+    c->device = device;
+    std::vector<float> rows(96 * 4);
+    cmf_rows(rows.data());
+    int rc = upload(c, &c->d_cmf, rows);
+    if (rc != SRT_OK) { delete c; return rc; }
+    if ((e = hipMalloc((void **)&c->d_counters, kCounters * sizeof(unsigned long long))) != hipSuccess ||
+        (e = hipMemset(c->d_counters, 0, kCounters * sizeof(unsigned long long))) != hipSuccess ||
+        (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess) {
+        int r = hip_fail(nullptr, e, "srt_create");
+        srt_destroy(c);
+        return r;
+    }
+    *out = c;
+    return SRT_OK;
+}
+
+void srt_destroy(srt_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    void *bufs[] = {c->d_nodes, c->d_tris, c->d_mat_sd, c->d_mat_par, c->d_bg, c->d_cmf, c->d_rng, c->d_fb, c->d_tiles, c->d_counters};
+    for (void *b : bufs) if (b) (void)hipFree(b);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    delete c;
+}
+
+const char *srt_last_error(const srt_ctx *ctx) { return ctx ? ctx->err.c_str() : global_error(); }
+
+int srt_upload_scene(srt_ctx *c, const srt_scene *s) {
+    if (!c || !s) return fail(c, SRT_ERR_INVALID, "srt_upload_scene: null argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    FlatScene f;
+    int rc = flatten_scene(*s, f);
+    if (rc != SRT_OK) return fail(c, rc, global_error());
+    if (render_lds_bytes(f.stack_depth) > 64 * 1024) return fail(c, SRT_ERR_BVH, "srt_upload_scene: BVH too deep for the LDS traversal stack");
+    if ((rc = upload(c, &c->d_nodes, f.nodes)) != SRT_OK) return rc;
+    if ((rc = upload(c, &c->d_tris, f.tris)) != SRT_OK) return rc;
+    if ((rc = upload(c, &c->d_mat_sd, f.mat_sd)) != SRT_OK) return rc;
+    if ((rc = upload(c, &c->d_mat_par, f.mat_par)) != SRT_OK) return rc;
+    if ((rc = upload(c, &c->d_bg, f.bg_sd)) != SRT_OK) return rc;
+    c->root_ref = f.root_ref; c->stack_depth = f.stack_depth; c->n_materials = (uint32_t)s->mats.size();
+    c->scene_ready = true;
+    return SRT_OK;
+}
+
+int srt_set_camera(srt_ctx *c, const srt_camera_data *cam) {
+    if (!c || !cam) return fail(c, SRT_ERR_INVALID, "srt_set_camera: null argument");
+    c->cam = *cam;
+    c->camera_ready = true;
+    return SRT_OK;
+}
+
+int srt_init_device_params(srt_ctx *c, uint32_t tx, uint32_t ty, uint32_t bx, uint32_t by, uint32_t chunk_w, uint32_t chunk_h,
+                           uint32_t spp, uint32_t bounce_limit, uint64_t seed) {
+    if (!c) return fail(c, SRT_ERR_INVALID, "srt_init_device_params: null ctx");
+    if (tx == 0 || ty == 0 || bx == 0 || by == 0 || chunk_w == 0 || chunk_h == 0)
+        return fail(c, SRT_ERR_INVALID, "srt_init_device_params: zero dimension");
+    const uint64_t lanes = (uint64_t)tx * ty * bx * by;
+    if (lanes > 0x7fffffffull) return fail(c, SRT_ERR_INVALID, "srt_init_device_params: grid too large");
+    HIP_TRY(c, hipSetDevice(c->device));
+    c->tx = tx; c->ty = ty; c->bx = bx; c->by = by; c->chunk_w = chunk_w; c->chunk_h = chunk_h;
+    c->spp = (uint16_t)spp; c->bounce = (uint16_t)bounce_limit;     // short_uint, rendering.cu:154 (Q17)
+    c->seed = seed; c->n_lanes = (uint32_t)lanes;
+    if (c->d_rng) { (void)hipFree(c->d_rng); c->d_rng = nullptr; }
+    if (c->d_fb) { (void)hipFree(c->d_fb); c->d_fb = nullptr; }
+    HIP_TRY(c, hipMalloc((void **)&c->d_rng, 6 * lanes * sizeof(uint32_t)));
+    HIP_TRY(c, hipMalloc((void **)&c->d_fb, kTilePlanes * lanes * sizeof(float)));
+    HIP_TRY(c, hipMemset(c->d_fb, 0, kTilePlanes * lanes * sizeof(float)));
+    HIP_TRY(c, launch_init_rng(c->d_rng, c->n_lanes, seed, nullptr));   // init_random_states, rendering.cu:330
+    HIP_TRY(c, hipDeviceSynchronize());
+    c->params_ready = true;
+    return SRT_OK;
+}
+
+int srt_set_partition(srt_ctx *c, uint32_t rank, uint32_t world) {
+    if (!c || world == 0 || rank >= world) return fail(c, SRT_ERR_INVALID, "srt_set_partition: need rank < world");
+    c->rank = rank; c->world = world;
+    return SRT_OK;
+}
+
+int srt_render_chunk(srt_ctx *c, uint32_t width, uint32_t height, uint32_t offx, uint32_t offy, void *stream) {
+    if (!c) return fail(c, SRT_ERR_INVALID, "srt_render_chunk: null ctx");
+    // reference: "Device parameters were not initialized, render aborted" (rendering.cu:247-250)
+    if (!c->scene_ready || !c->camera_ready || !c->params_ready)
+        return fail(c, SRT_ERR_INVALID, "srt_render_chunk: scene, camera and device parameters must be set first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    width = (uint16_t)width; height = (uint16_t)height; offx = (uint16_t)offx; offy = (uint16_t)offy;   // rendering.cu:245 (Q17)
+    c->last_w = width; c->last_h = height; c->last_offx = offx; c->last_offy = offy;
+    // tiles cover the pixels the reference grid can address
+    const uint32_t cover_w = std::min<uint32_t>(width, c->tx * c->bx), cover_h = std::min<uint32_t>(height, c->ty * c->by);
+    c->tiles_x = (cover_w + 7) / 8; c->tiles_y = (cover_h + 7) / 8;
+    c->n_tiles = c->tiles_x * c->tiles_y;
+    c->tiles_padded = (c->n_tiles + c->world - 1) / c->world;
+    c->tiles_local = c->n_tiles > c->rank ? (c->n_tiles - c->rank + c->world - 1) / c->world : 0;
+    const size_t need = (size_t)std::max<uint32_t>(c->tiles_padded, 1) * kTilePlanes * kTileLanes;
+    if (need > c->tiles_capacity) {
+        if (c->d_tiles) { (void)hipFree(c->d_tiles); c->d_tiles = nullptr; }
+        HIP_TRY(c, hipMalloc((void **)&c->d_tiles, need * sizeof(float)));
+        c->tiles_capacity = need;
+    }
+    HIP_TRY(c, hipMemsetAsync(c->d_tiles, 0, need * sizeof(float), st));
+    HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, kCounters * sizeof(unsigned long long), st));
+    RenderParams p;
+    fill_params(c, p);
+    p.width = width; p.height = height; p.offx = offx; p.offy = offy;
+    p.tiles_x = c->tiles_x; p.tiles_y = c->tiles_y; p.n_tiles = c->n_tiles;
+    HIP_TRY(c, hipEventRecord(c->ev0, st));
+    HIP_TRY(c, launch_render(p, c->tiles_local, c->count_traversal, st));
+    HIP_TRY(c, hipEventRecord(c->ev1, st));
+    c->timed = true;
+    c->last_paths = 0;   // filled by srt_get_stats from the tile ownership
+    return SRT_OK;
+}
+
+int srt_synchronize(srt_ctx *c) {
+    if (!c) return fail(c, SRT_ERR_INVALID, "srt_synchronize: null ctx");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipDeviceSynchronize());
+    return SRT_OK;
+}
+
+int srt_tile_buffer(srt_ctx *c, void **dev_ptr, size_t *n_floats, uint32_t *tiles_local, uint32_t *tiles_padded) {
+    if (!c || !c->d_tiles) return fail(c, SRT_ERR_INVALID, "srt_tile_buffer: nothing rendered yet");
+    if (dev_ptr) *dev_ptr = c->d_tiles;
+    if (n_floats) *n_floats = (size_t)c->tiles_padded * kTilePlanes * kTileLanes;
+    if (tiles_local) *tiles_local = c->tiles_local;
+    if (tiles_padded) *tiles_padded = c->tiles_padded;
+    return SRT_OK;
+}
+
+int srt_scatter_tiles(srt_ctx *c, const void *dev_gathered, void *stream) {
+    if (!c || !c->d_fb || !c->d_tiles) return fail(c, SRT_ERR_INVALID, "srt_scatter_tiles: nothing rendered yet");
+    if (!dev_gathered) {
+        if (c->world != 1) return fail(c, SRT_ERR_INVALID, "srt_scatter_tiles: a gathered buffer is required when world > 1");
+        dev_gathered = c->d_tiles;
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    ScatterParams sp;
+    memset(&sp, 0, sizeof(sp));
+    sp.gathered = (const float *)dev_gathered;
+    for (int p = 0; p < kTilePlanes; p++) sp.fb[p] = c->d_fb + (size_t)p * c->n_lanes;
+    sp.width = c->last_w; sp.height = c->last_h;
+    sp.tx = c->tx; sp.ty = c->ty; sp.bx = c->bx; sp.by = c->by;
+    sp.tiles_x = c->tiles_x; sp.n_tiles = c->n_tiles; sp.world = c->world; sp.tiles_padded = c->tiles_padded;
+    HIP_TRY(c, launch_scatter(sp, (hipStream_t)stream));
+    return SRT_OK;
+}
+
+int srt_dev_fb(srt_ctx *c, void **r, void **g, void **b, size_t *n_floats) {
+    if (!c || !c->d_fb) return fail(c, SRT_ERR_INVALID, "srt_dev_fb: device parameters not initialised");
+    if (r) *r = c->d_fb;
+    if (g) *g = c->d_fb + (size_t)c->n_lanes;
+    if (b) *b = c->d_fb + 2 * (size_t)c->n_lanes;
+    if (n_floats) *n_floats = c->n_lanes;
+    return SRT_OK;
+}
+
+static int read_planes(srt_ctx *c, int first_plane, float *p0, float *p1, float *p2) {
+    if (!c || !c->d_fb) return fail(c, SRT_ERR_INVALID, "read: device parameters not initialised");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipDeviceSynchronize());
+    float *dst[3] = {p0, p1, p2};
+    for (int k = 0; k < 3; k++)
+        if (dst[k]) HIP_TRY(c, hipMemcpy(dst[k], c->d_fb + (size_t)(first_plane + k) * c->n_lanes, (size_t)c->n_lanes * sizeof(float), hipMemcpyDeviceToHost));
+    return SRT_OK;
+}
+
+int srt_read_fb(srt_ctx *c, float *r, float *g, float *b) { return read_planes(c, 0, r, g, b); }
+
+int srt_read_fb_aux(srt_ctx *c, int which, float *p0, float *p1, float *p2) {
+    if (which != 1 && which != 2) return fail(c, SRT_ERR_INVALID, "srt_read_fb_aux: which must be 1 (sRGB) or 2 (XYZ)");
+    return read_planes(c, 3 * which, p0, p1, p2);
+}
+
+int srt_read_fb_rowmajor(srt_ctx *c, float *r, float *g, float *b, uint32_t image_width, uint32_t image_height) {
+    if (!c || !c->d_fb || !r || !g || !b || image_width == 0 || image_height == 0) return fail(c, SRT_ERR_INVALID, "srt_read_fb_rowmajor: bad argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t n = (size_t)image_width * image_height;
+    float *tmp = nullptr;
+    HIP_TRY(c, hipMalloc((void **)&tmp, 3 * n * sizeof(float)));
+    hipError_t e = hipMemset(tmp, 0, 3 * n * sizeof(float));
+    // seed the staging image with the caller's current content so that chunks accumulate like update_fb does
+    if (e == hipSuccess) e = hipMemcpy(tmp, r, n * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(tmp + n, g, n * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(tmp + 2 * n, b, n * sizeof(float), hipMemcpyHostToDevice);
+    const float *src[3] = {c->d_fb, c->d_fb + (size_t)c->n_lanes, c->d_fb + 2 * (size_t)c->n_lanes};
+    float *dst[3] = {tmp, tmp + n, tmp + 2 * n};
+    if (e == hipSuccess) e = launch_unswizzle(src, dst, c->tx, c->ty, c->bx, c->by, c->last_w, c->last_h, c->last_offx, c->last_offy, image_width, image_height, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(r, tmp, n * sizeof(float), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(g, tmp + n, n * sizeof(float), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(b, tmp + 2 * n, n * sizeof(float), hipMemcpyDeviceToHost);
+    (void)hipFree(tmp);
+    if (e != hipSuccess) return hip_fail(c, e, "srt_read_fb_rowmajor");
+    return SRT_OK;
+}
+
+int srt_get_stats(srt_ctx *c, srt_stats *out) {
+    if (!c || !out) return fail(c, SRT_ERR_INVALID, "srt_get_stats: null argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipDeviceSynchronize());
+    unsigned long long h[kCounters];
+    HIP_TRY(c, hipMemcpy(h, c->d_counters, sizeof(h), hipMemcpyDeviceToHost));
+    memset(out, 0, sizeof(*out));
+    out->rays = h[0]; out->node_visits = h[1]; out->tri_tests = h[2]; out->box_tests = h[3];
+    // paths = spp * pixels owned by this rank
+    uint64_t pixels = 0;
+    for (uint32_t t = c->rank; t < c->n_tiles; t += c->world) {
+        const uint32_t tx0 = (t % c->tiles_x) * 8, ty0 = (t / c->tiles_x) * 8;
+        const uint32_t lim_w = std::min<uint32_t>(c->last_w, c->tx * c->bx), lim_h = std::min<uint32_t>(c->last_h, c->ty * c->by);
+        const uint32_t w = tx0 < lim_w ? std::min<uint32_t>(8, lim_w - tx0) : 0, hgt = ty0 < lim_h ? std::min<uint32_t>(8, lim_h - ty0) : 0;
+        pixels += (uint64_t)w * hgt;
+    }
+    out->paths = pixels * c->spp;
+    return SRT_OK;
+}
+
+int srt_set_count_traversal(srt_ctx *c, int on) {
+    if (!c) return fail(c, SRT_ERR_INVALID, "srt_set_count_traversal: null ctx");
+    c->count_traversal = on != 0;
+    return SRT_OK;
+}
+
+int srt_last_kernel_ms(srt_ctx *c, float *ms) {
+    if (!c || !ms || !c->timed) return fail(c, SRT_ERR_INVALID, "srt_last_kernel_ms: nothing rendered yet");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipEventSynchronize(c->ev1));
+    HIP_TRY(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return SRT_OK;
+}
+
+int srt_trace_rays(srt_ctx *c, const float *rays, size_t n, float *out) {
+    if (!c || !c->scene_ready || (!rays && n) || (!out && n)) return fail(c, SRT_ERR_INVALID, "srt_trace_rays: scene not uploaded / bad argument");
+    if (n == 0) return SRT_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    float *d_in = nullptr, *d_out = nullptr;
+    HIP_TRY(c, hipMalloc((void **)&d_in, 6 * n * sizeof(float)));
+    hipError_t e = hipMalloc((void **)&d_out, 4 * n * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(d_in, rays, 6 * n * sizeof(float), hipMemcpyHostToDevice);
+    RenderParams p;
+    fill_params(c, p);
+    if (e == hipSuccess) e = launch_trace(p, d_in, n, d_out, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(out, d_out, 4 * n * sizeof(float), hipMemcpyDeviceToHost);
+    (void)hipFree(d_in);
+    if (d_out) (void)hipFree(d_out);
+    if (e != hipSuccess) return hip_fail(c, e, "srt_trace_rays");
+    return SRT_OK;
+}
+
+int srt_device_op_sweep(srt_ctx *c, int which, const float *a, const float *b, size_t n, float *out) {
+    if (!c || !a || !b || !out) return fail(c, SRT_ERR_INVALID, "srt_device_op_sweep: null argument");
+    if (n == 0) return SRT_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    float *d = nullptr;
+    HIP_TRY(c, hipMalloc((void **)&d, 3 * n * sizeof(float)));
+    hipError_t e = hipMemcpy(d, a, n * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d + n, b, n * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = launch_op_sweep(which, d, d + n, n, d + 2 * n, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(out, d + 2 * n, n * sizeof(float), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return hip_fail(c, e, "srt_device_op_sweep");
+    return SRT_OK;
+}
+
+}  // extern "C"

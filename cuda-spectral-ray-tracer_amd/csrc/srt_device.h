@@ -1,0 +1,276 @@
+// srt_device.h -- gfx950 device arithmetic of the spectral path tracer.
+//
+// Every function restates one piece of the reference's device library (file:line cited) with the
+// reference's IEEE-754 fp32 operation order.  This translation unit is compiled with
+// -ffp-contract=off and correctly rounded fp32 divide/sqrt, no fast-math: the parity tests require
+// bit-identical results to the CPU oracle, because the estimator's discrete decisions (hit/miss at
+// an edge, reflect/refract, rejection accept) flip on 1-ulp differences (DESIGN.md "Exactness").
+//
+// Data layout is this build's own (DESIGN.md "HBM layout"): paired-child 64-byte BVH records,
+// 48-byte triangle records with the 2-D projected vertices, spectra as (s[k], s[k+1]) pairs.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "srt_powf.h"
+
+namespace srt {
+
+constexpr int kCieSamples = 95;
+constexpr int kWavelengths = 7;
+constexpr float kLambdaMin = 360.0f;
+constexpr float kLambdaMax = 830.0f;
+constexpr float kEpsilon = 0.0001f;      // materials/material.cuh:14
+constexpr float kFltMax = 3.402823466e+38f;
+
+// one out-of-line copy of srt_powf per kernel image (it is called from four places)
+__device__ __noinline__ static float dev_powf(float x, float y) { return srt_powf(x, y); }
+
+// ------------------------------------------------------------------------------------------------
+// vec3 (math/vec3.cuh:119-163).  dot is left-associated x+y+z (:149-153).
+// ------------------------------------------------------------------------------------------------
+struct V3 { float x, y, z; };
+__device__ __forceinline__ V3 mk(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 operator-(V3 a) { return mk(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ V3 operator*(float t, V3 v) { return mk(t * v.x, t * v.y, t * v.z); }
+__device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ float length_squared(V3 v) { return v.x * v.x + v.y * v.y + v.z * v.z; }   // :66-72
+// unit_vector = v / len = (1/len) * v  (:144-147,:161)
+__device__ __forceinline__ V3 unit_vector(V3 v) { float k = 1.0f / sqrtf(length_squared(v)); return k * v; }
+// reflect = v - 2*dot(v,n)*n  (:180-183)
+__device__ __forceinline__ V3 reflect(V3 v, V3 n) { return v - (2.0f * dot(v, n)) * n; }
+// refract (:199-205)
+__device__ __forceinline__ V3 refract(V3 uv, V3 n, float etai_over_etat) {
+    float cos_theta = fminf(dot(-uv, n), 1.0f);
+    V3 r_out_perp = etai_over_etat * (uv + cos_theta * n);
+    V3 r_out_parallel = (-sqrtf(fabsf(1.0f - length_squared(r_out_perp)))) * n;
+    return r_out_perp + r_out_parallel;
+}
+__device__ __forceinline__ bool near_zero(V3 v) {   // :93-98
+    const float s = 1e-8f;
+    return (fabsf(v.x) < s) && (fabsf(v.y) < s) && (fabsf(v.z) < s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// RNG: cuRAND XORWOW core (curand_init with subsequence 0 / offset 0, curand, curand_uniform),
+// restated from the published definition; call sites rendering/rendering.cu:137,
+// utils/cuda_utility.cu:19-49.  Six 32-bit words per lane.
+// ------------------------------------------------------------------------------------------------
+struct Rng { uint32_t d, v0, v1, v2, v3, v4; };
+
+__device__ __forceinline__ void rng_seed(Rng &s, uint64_t seed) {
+    uint32_t s0 = ((uint32_t)seed) ^ 0xaad26b49u;
+    uint32_t s1 = ((uint32_t)(seed >> 32)) ^ 0xf7dcefddu;
+    uint32_t t0 = 1099087573u * s0;
+    uint32_t t1 = 2591861531u * s1;
+    s.d = 6615241u + t1 + t0;
+    s.v0 = 123456789u + t0;
+    s.v1 = 362436069u ^ t0;
+    s.v2 = 521288629u + t1;
+    s.v3 = 88675123u ^ t1;
+    s.v4 = 5783321u + t0;
+}
+__device__ __forceinline__ uint32_t rng_next(Rng &s) {
+    uint32_t t = s.v0 ^ (s.v0 >> 2);
+    s.v0 = s.v1; s.v1 = s.v2; s.v2 = s.v3; s.v3 = s.v4;
+    s.v4 = (s.v4 ^ (s.v4 << 4)) ^ (t ^ (t << 1));
+    s.d += 362437u;
+    return s.v4 + s.d;
+}
+// cuda_random_float(): curand_uniform in (0,1]  (utils/cuda_utility.cu:19-26)
+__device__ __forceinline__ float rng_uniform(Rng &s) {
+    return (float)rng_next(s) * 2.3283064e-10f + (2.3283064e-10f / 2.0f);
+}
+// cuda_random_float(min,max): u*(max-min)+min  (utils/cuda_utility.cu:28-41)
+__device__ __forceinline__ float rng_range(Rng &s, float mn, float mx) {
+    float range_width = mx - mn;
+    float random = rng_uniform(s);
+    return random * range_width + mn;
+}
+// random_in_unit_sphere (math/vec3.cuh:210-218); draws x, y, z in that order (DESIGN.md D1 / SURVEY Q19)
+__device__ __forceinline__ V3 random_in_unit_sphere(Rng &s) {
+    for (;;) {
+        float x = rng_range(s, -1.0f, 1.0f);
+        float y = rng_range(s, -1.0f, 1.0f);
+        float z = rng_range(s, -1.0f, 1.0f);
+        V3 p = mk(x, y, z);
+        if (length_squared(p) < 1.0f) return p;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// spectrum (spectrum/spectrum.cu:11-48)
+// ------------------------------------------------------------------------------------------------
+// spectrum_interp's index/weight part (:11-20): x = (lambda-360)*(94/470); off = clamp((int)x, 0, 93); w = x - off
+__device__ __forceinline__ void interp_coords(float lambda, int &offset, float &weight) {
+    lambda -= kLambdaMin;
+    lambda *= ((float)kCieSamples - 1) / (kLambdaMax - kLambdaMin);
+    offset = (int)lambda;
+    if (offset < 0) offset = 0;
+    if (offset > kCieSamples - 2) offset = kCieSamples - 2;
+    weight = lambda - (float)offset;
+}
+// (:21) on a stored (s[k], s[k+1]) pair
+__device__ __forceinline__ float interp_pair(float2 pr, float weight) { return (1.0f - weight) * pr.x + weight * pr.y; }
+
+// init_hero_wavelength (:31-48): hero = u*470+360; next = prev + 470/7 wrapped into [360,830]
+__device__ __forceinline__ void hero_wavelengths(Rng &s, float (&wl)[kWavelengths]) {
+    float step = (kLambdaMax - kLambdaMin) / (float)kWavelengths;
+    float hero = rng_range(s, kLambdaMin, kLambdaMax);
+    wl[0] = hero;
+    float lambda = hero;
+#pragma unroll
+    for (int i = 1; i < kWavelengths; i++) {
+        lambda += step;
+        if (lambda > kLambdaMax) {
+            float remainder = lambda - kLambdaMax;
+            lambda = kLambdaMin + remainder;
+        }
+        wl[i] = lambda;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// colour (color/color.cu:15-49)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float correct_channel(float value) {   // :15-22
+    return value < 0.0f ? 0.0f
+         : (value < 0.0031308f ? 12.92f * value
+         : (value < 1.0f ? ((1.055f * dev_powf(value, 0.416666f)) - 0.055f) : 1.0f));
+}
+
+// ------------------------------------------------------------------------------------------------
+// refraction / materials (refraction/sellmeier.cu:11-22, materials/material.cu:39-53)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sellmeier_index(float b0, float b1, float b2, float c0, float c1, float c2, float lambda) {
+    lambda *= 1e-3f;
+    float l2 = lambda * lambda;
+    float index = 1.0f + (b0 * l2) / (l2 - c0) + (b1 * l2) / (l2 - c1) + (b2 * l2) / (l2 - c2);
+    return sqrtf(index);
+}
+__device__ __forceinline__ float reflectance(float cosine, float ref_idx) {
+    float r0 = (1.0f - ref_idx) / (1.0f + ref_idx);
+    r0 = r0 * r0;
+    return r0 + (1.0f - r0) * dev_powf(1.0f - cosine, 5.0f);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Intersection tests
+// ------------------------------------------------------------------------------------------------
+// Triangle record (3 x float4):
+//   a = { n.x, n.y, n.z, D }                      tri.cuh:93-94 (normal, D)
+//   b = { v0[w], v0[h], v1[w], v1[h] }            vertices projected on the aa_plane axes (tri.cu:153-176)
+//   c = { v2[w], v2[h], bits(flags), 0 }          flags: bit0 = w axis is y, bit1 = h axis is z,
+//                                                 bit2 = clockwise, bits 8.. = mat_index
+constexpr uint32_t kTriWIsY = 1u, kTriHIsZ = 2u, kTriClockwise = 4u;
+
+// tri::hit (primitives/tri.cu:3-45) without the record write-back; returns t through `t_out`.
+__device__ __forceinline__ bool tri_test(const float4 *__restrict__ tris, int tri, V3 o, V3 d, float tmin, float tmax,
+                                         float &t_out) {
+    const float4 a = tris[3 * tri + 0];
+    const V3 n = mk(a.x, a.y, a.z);
+    float denom = dot(n, d);
+    if (fabsf(denom) < 1e-8f) return false;
+    float t = (a.w - dot(n, o)) / denom;
+    if (!(tmin <= t && t <= tmax)) return false;            // interval::contains, math/interval.cuh:44-46
+    const float4 b = tris[3 * tri + 1];
+    const float4 c = tris[3 * tri + 2];
+    const uint32_t flags = __float_as_uint(c.z);
+    // intersection = orig + t*dir (ray.cuh:31-34), only the two projected components are needed here
+    const bool wy = flags & kTriWIsY, hz = flags & kTriHIsZ;
+    float pw = (wy ? o.y : o.x) + t * (wy ? d.y : d.x);
+    float ph = (hz ? o.z : o.y) + t * (hz ? d.z : d.y);
+    // is_interior_faster (tri.cu:121-128) with double_signed_area_2D(v1,v2,v3) =
+    //   (v1[w]-v3[w])*(v2[h]-v3[h]) - (v2[w]-v3[w])*(v1[h]-v3[h])   (tri.cu:181)
+    float a1 = (pw - b.z) * (b.y - b.w) - (b.x - b.z) * (ph - b.w);   // (p, v0, v1)
+    float a2 = (pw - c.x) * (b.w - c.y) - (b.z - c.x) * (ph - c.y);   // (p, v1, v2)
+    float a3 = (pw - b.x) * (c.y - b.y) - (c.x - b.x) * (ph - b.y);   // (p, v2, v0)
+    bool inside = (flags & kTriClockwise) ? (a1 >= 0.f && a2 >= 0.f && a3 >= 0.f) : (a1 <= 0.f && a2 <= 0.f && a3 <= 0.f);
+    if (!inside) return false;
+    t_out = t;
+    return true;
+}
+
+// aabb::hit (bvh/aabb.cu:7-40) for one child box with the per-ray reciprocal hoisted
+// (inv = 1/dir is the same IEEE division the reference redoes per box).  The per-axis early-outs of
+// the reference are equivalent to the single final test because min only grows and max only shrinks;
+// NaN t0/t1 are ignored by both forms (comparisons false / fmaxf,fminf return the other operand).
+__device__ __forceinline__ bool box_test(float lox, float hix, float loy, float hiy, float loz, float hiz, V3 o, V3 inv,
+                                         float tmin, float tmax) {
+    const bool px = inv.x >= 0, py = inv.y >= 0, pz = inv.z >= 0;
+    float t0x = ((px ? lox : hix) - o.x) * inv.x, t1x = ((px ? hix : lox) - o.x) * inv.x;
+    float t0y = ((py ? loy : hiy) - o.y) * inv.y, t1y = ((py ? hiy : loy) - o.y) * inv.y;
+    float t0z = ((pz ? loz : hiz) - o.z) * inv.z, t1z = ((pz ? hiz : loz) - o.z) * inv.z;
+    float mn = fmaxf(fmaxf(fmaxf(tmin, t0x), t0y), t0z);
+    float mx = fminf(fminf(fminf(tmax, t1x), t1y), t1z);
+    return !(mx <= mn);
+}
+
+// BVH paired-child record (4 x float4 = 64 B, one per INTERNAL node of the reference's binary tree):
+//   q0 = { L.xmin, L.xmax, L.ymin, L.ymax }   q1 = { L.zmin, L.zmax, R.xmin, R.xmax }
+//   q2 = { R.ymin, R.ymax, R.zmin, R.zmax }   q3 = { bits(lref), bits(rref), 0, 0 }
+// ref >= 0: index of the child's own record (internal child; its box is the one stored here);
+// ref <  0: ~ref is a triangle index (leaf child; leaves are tested directly, bvh.cu:73-76, no box).
+
+// bvh::hit (bvh/bvh.cu:98-166): closest hit, left child then right child, "t <= closest" accepts (Q11),
+// push right iff both internal children are hit.  `stack` is this lane's column of the LDS stack
+// (element k at stack[k*64]).  Returns the hit triangle index or -1; t in `closest`.
+template <bool COUNT>
+__device__ __forceinline__ int bvh_closest_hit(const float4 *__restrict__ nodes, const float4 *__restrict__ tris,
+                                               int root_ref, V3 o, V3 d, uint32_t *stack, float &closest, bool active,
+                                               uint32_t &n_iters, uint32_t &n_tri, uint32_t &n_box) {
+    float c = kFltMax;
+    int hit_tri = -1;
+    const V3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    int node = -1;
+    if (active) {
+        if (root_ref < 0) {   // root is a leaf (bvh.cu:114-119)
+            float t;
+            if (COUNT) n_tri++;
+            if (tri_test(tris, ~root_ref, o, d, 0.0f, c, t)) { c = t; hit_tri = ~root_ref; }
+        } else {
+            node = root_ref;
+        }
+    }
+    int sp = 0;
+    while (__ballot(node >= 0) != 0ull) {
+        if (node >= 0) {
+            const float4 q0 = nodes[4 * node + 0];
+            const float4 q1 = nodes[4 * node + 1];
+            const float4 q2 = nodes[4 * node + 2];
+            const float4 q3 = nodes[4 * node + 3];
+            const int lref = (int)__float_as_uint(q3.x), rref = (int)__float_as_uint(q3.y);
+            if (COUNT) n_iters++;
+            bool trav_l = false, trav_r = false;
+            if (lref < 0) {
+                float t;
+                if (COUNT) n_tri++;
+                if (tri_test(tris, ~lref, o, d, 0.0f, c, t)) { c = t; hit_tri = ~lref; }
+            } else {
+                if (COUNT) n_box++;
+                trav_l = box_test(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, inv, 0.0f, c);
+            }
+            if (rref < 0) {
+                float t;
+                if (COUNT) n_tri++;
+                if (tri_test(tris, ~rref, o, d, 0.0f, c, t)) { c = t; hit_tri = ~rref; }
+            } else {
+                if (COUNT) n_box++;
+                trav_r = box_test(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, inv, 0.0f, c);
+            }
+            if (!trav_l && !trav_r) {
+                if (sp == 0) node = -1;
+                else { sp--; node = (int)stack[sp * 64]; }
+            } else {
+                node = trav_l ? lref : rref;
+                if (trav_l && trav_r) { stack[sp * 64] = (uint32_t)rref; sp++; }
+            }
+        }
+    }
+    closest = c;
+    return hit_tri;
+}
+
+}  // namespace srt

@@ -1,0 +1,60 @@
+// srt_internal.h -- shared between the C-ABI implementation (srt_capi.cpp) and the HIP kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+namespace srt {
+
+constexpr int kTilePlanes = 9;      // quantised rgb | unquantised sRGB | XYZ sums
+constexpr int kTileLanes = 64;      // one wave = one 8x8 pixel tile
+constexpr int kCounters = 8;        // rays, node_visits, tri_tests, box_tests, ...
+
+// Kernel arguments of one render launch.  All pointers are device pointers.
+struct RenderParams {
+    // scene (HBM layout: DESIGN.md)
+    const float4 *nodes;       // 4 float4 per internal node (paired-child record)
+    const float4 *tris;        // 3 float4 per triangle
+    const float2 *mat_sd;      // per material 96 pairs (94 used): (sd[k], sd[k+1])
+    const float4 *mat_par;     // per material 2 float4: {bits(type), fuzz, B0, B1}, {B2, C0, C1, C2}
+    const float2 *bg_sd;       // 96 pairs (94 used) of the background spectrum
+    const float4 *cmf;         // 96 rows (95 used): { x_bar, y_bar, z_bar, D65n }
+    int root_ref;              // >= 0 record index, < 0: ~triangle (single-leaf tree)
+    int stack_depth;           // LDS stack entries per lane
+    uint32_t n_materials;
+    // camera_data (rendering/rendering.cuh:28-36)
+    float du[3], dv[3], p00[3];
+    float defocus_angle;
+    float center[3], disk_u[3], disk_v[3];
+    // launch geometry
+    uint32_t width, height, offx, offy;   // chunk (rendering.cu:153)
+    uint32_t tx, ty, bx, by;              // the reference's block / grid dims: define idx and the RNG seed
+    uint32_t spp, bounce_limit;
+    uint32_t tiles_x, tiles_y, n_tiles;   // 8x8 tiles covering the chunk
+    uint32_t rank, world;                 // this launch renders tiles t with t % world == rank
+    // state / outputs
+    uint32_t *rng;                        // SoA: 6 planes of n_lanes words, indexed by the block-linear idx
+    uint32_t n_lanes;                     // tx*ty*bx*by
+    float *tile_out;                      // [local tile][plane][lane]
+    unsigned long long *counters;
+};
+
+struct ScatterParams {
+    const float *gathered;     // [rank][tiles_padded][plane][lane]
+    float *fb[9];              // block-linear planes: r g b | lin r g b | X Y Z
+    uint32_t width, height;
+    uint32_t tx, ty, bx, by;
+    uint32_t tiles_x, n_tiles, world, tiles_padded;
+};
+
+hipError_t launch_init_rng(uint32_t *rng, uint32_t n_lanes, uint64_t seed, hipStream_t st);
+hipError_t launch_render(const RenderParams &p, uint32_t tiles_local, bool count_traversal, hipStream_t st);
+hipError_t launch_scatter(const ScatterParams &p, hipStream_t st);
+hipError_t launch_unswizzle(const float *const src[3], float *const dst[3], uint32_t tx, uint32_t ty, uint32_t bx, uint32_t by,
+                            uint32_t n_cols, uint32_t n_rows, uint32_t offx, uint32_t offy, uint32_t image_width,
+                            uint32_t image_height, hipStream_t st);
+hipError_t launch_trace(const RenderParams &p, const float *rays, size_t n, float *out, hipStream_t st);
+hipError_t launch_op_sweep(int which, const float *a, const float *b, size_t n, float *out, hipStream_t st);
+size_t render_lds_bytes(int stack_depth);
+
+}  // namespace srt

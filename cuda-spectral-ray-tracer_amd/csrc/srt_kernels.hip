@@ -1,0 +1,422 @@
+// srt_kernels.hip -- hand-written gfx950 kernels of the spectral path tracer.
+//
+// render_kernel is the whole hot path of the reference's spectral_render_kernel
+// (rendering/rendering.cu:151-235): one lane = one pixel, one wave = one 8x8 pixel tile,
+// samples and bounces looped inside the lane so the per-pixel XORWOW stream is consumed in the
+// reference's order.  Unlike the reference (one thread per pixel walking a pointer tree with a
+// 64-entry local-memory stack and a 36-byte hit record in shared memory) the lane is a small state
+// machine: paths are regenerated in place, the whole wave stays in the traversal loop while any lane
+// still has nodes to visit (64-bit __ballot), the traversal stack lives in LDS (one column per lane,
+// lane-interleaved so a push/pop is bank-conflict free), BVH nodes are 64-byte paired-child records
+// fetched with four coalesced-per-lane 16-byte loads, and the hit record is just (t, triangle).
+//
+// Build: hipcc --offload-arch=gfx950 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt
+#include "srt_device.h"
+#include "srt_internal.h"
+
+namespace srt {
+
+// LDS map (bytes): [0, 1536) colour matching rows (96 float4) | [1536, 2304) background pairs
+// (96 float2) | [2304, ...) traversal stack, stack_depth * 64 lanes * 4 B.
+constexpr int kLdsCmfF4 = 96;
+constexpr int kLdsBgF2 = 96;
+size_t render_lds_bytes(int stack_depth) {
+    return (size_t)kLdsCmfF4 * 16 + (size_t)kLdsBgF2 * 8 + (size_t)(stack_depth < 1 ? 1 : stack_depth) * 64 * 4;
+}
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// block-linear index of chunk pixel (i, j): idx = ty*28+tx + 448*(by*gridDim.x+bx)  (rendering.cu:156-165)
+__device__ __forceinline__ uint32_t block_linear_idx(uint32_t i, uint32_t j, uint32_t tx, uint32_t ty, uint32_t bx) {
+    uint32_t gbx = i / tx, gby = j / ty;
+    uint32_t lx = i - gbx * tx, ly = j - gby * ty;
+    return ly * tx + lx + tx * ty * (gby * bx + gbx);
+}
+
+// init_random_states (rendering.cu:120-138): curand_init(seed + idx, 0, 0)
+__global__ void init_rng_kernel(uint32_t *rng, uint32_t n_lanes, uint64_t seed) {
+    uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_lanes) return;
+    Rng s;
+    rng_seed(s, seed + idx);
+    rng[0 * (size_t)n_lanes + idx] = s.d;
+    rng[1 * (size_t)n_lanes + idx] = s.v0;
+    rng[2 * (size_t)n_lanes + idx] = s.v1;
+    rng[3 * (size_t)n_lanes + idx] = s.v2;
+    rng[4 * (size_t)n_lanes + idx] = s.v3;
+    rng[5 * (size_t)n_lanes + idx] = s.v4;
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(64) void render_kernel(const RenderParams P) {
+    extern __shared__ float4 lds4[];
+    float4 *s_cmf = lds4;
+    float2 *s_bg = reinterpret_cast<float2 *>(lds4 + kLdsCmfF4);
+    uint32_t *s_stack = reinterpret_cast<uint32_t *>(lds4 + kLdsCmfF4 + kLdsBgF2 / 2);
+    const uint32_t lane = threadIdx.x;
+
+    for (uint32_t k = lane; k < kLdsCmfF4; k += 64) s_cmf[k] = P.cmf[k];
+    for (uint32_t k = lane; k < kLdsBgF2; k += 64) s_bg[k] = P.bg_sd[k];
+    __syncthreads();
+
+    const uint32_t tile = P.rank + P.world * blockIdx.x;
+    const uint32_t tile_x = tile % P.tiles_x, tile_y = tile / P.tiles_x;
+    const uint32_t i = tile_x * 8u + (lane & 7u);          // chunk-relative column (rendering.cu:156)
+    const uint32_t j = tile_y * 8u + (lane >> 3);          // chunk-relative row    (rendering.cu:157)
+    // lanes outside the chunk (or outside the reference grid) never touch RNG or output (rendering.cu:205)
+    bool alive = (tile < P.n_tiles) && (i < P.width) && (j < P.height) && (i / P.tx < P.bx) && (j / P.ty < P.by);
+    const uint32_t idx = alive ? block_linear_idx(i, j, P.tx, P.ty, P.bx) : 0u;
+    const bool in_image = alive;
+
+    Rng rs;
+    rs.d = rs.v0 = rs.v1 = rs.v2 = rs.v3 = rs.v4 = 0u;
+    if (alive) {   // rendering.cu:209
+        rs.d = P.rng[0 * (size_t)P.n_lanes + idx];
+        rs.v0 = P.rng[1 * (size_t)P.n_lanes + idx];
+        rs.v1 = P.rng[2 * (size_t)P.n_lanes + idx];
+        rs.v2 = P.rng[3 * (size_t)P.n_lanes + idx];
+        rs.v3 = P.rng[4 * (size_t)P.n_lanes + idx];
+        rs.v4 = P.rng[5 * (size_t)P.n_lanes + idx];
+    }
+
+    const V3 du = mk(P.du[0], P.du[1], P.du[2]), dv = mk(P.dv[0], P.dv[1], P.dv[2]);
+    // pixel_center = p00 + (float)i*du + (float)j*dv with i, j including the chunk offset (rendering.cu:76,221)
+    const V3 pixel_center = (mk(P.p00[0], P.p00[1], P.p00[2]) + (float)(P.offx + i) * du) + (float)(P.offy + j) * dv;
+    const V3 cam_center = mk(P.center[0], P.center[1], P.center[2]);
+
+    V3 acc = mk(0.f, 0.f, 0.f);          // pixel_color (rendering.cu:212)
+    V3 ro = mk(0.f, 0.f, 0.f), rd = mk(0.f, 0.f, 1.f);
+    float wl[kWavelengths], pw[kWavelengths];
+#pragma unroll
+    for (int k = 0; k < kWavelengths; k++) { wl[k] = 0.f; pw[k] = 0.f; }
+    uint32_t valid = 0, sample = 0, bounce = 0;
+    bool need_path = true;
+    uint32_t n_rays = 0, n_iters = 0, n_tri = 0, n_box = 0;
+    uint32_t *my_stack = s_stack + lane;
+
+    for (;;) {
+        // ---- path regeneration: renderer::get_ray (rendering.cu:66-87) --------------------------------
+        if (alive && need_path) {
+            if (sample == P.spp) {
+                alive = false;
+            } else {
+                float px = -0.5f + rng_uniform(rs);                       // pixel_sample_square, :49-56
+                float py = -0.5f + rng_uniform(rs);
+                V3 pixel_sample = pixel_center + (px * du + py * dv);
+                V3 origin = cam_center;
+                if (!(P.defocus_angle <= 0.0f)) {                          // defocus_disk_sample, :42-47
+                    float dx, dy;
+                    for (;;) {                                             // random_in_unit_disk, vec3.cuh:240-246
+                        dx = rng_range(rs, -1.0f, 1.0f);
+                        dy = rng_range(rs, -1.0f, 1.0f);
+                        if ((dx * dx + dy * dy) + 0.0f * 0.0f < 1.0f) break;
+                    }
+                    origin = (cam_center + dx * mk(P.disk_u[0], P.disk_u[1], P.disk_u[2])) +
+                             dy * mk(P.disk_v[0], P.disk_v[1], P.disk_v[2]);
+                }
+                ro = origin;
+                rd = pixel_sample - origin;                                // not normalised (Q10)
+                hero_wavelengths(rs, wl);                                  // ray ctor -> init_spectrum, ray.cuh:37-50
+#pragma unroll
+                for (int k = 0; k < kWavelengths; k++) pw[k] = 1.0f;
+                valid = kWavelengths;
+                sample++;
+                bounce = 0;
+                need_path = false;
+            }
+        }
+        if (__ballot(alive) == 0ull) break;
+
+        // ---- renderer::ray_bounce, one iteration of its loop (rendering.cu:22-36) ----------------------
+        bool end_path = false;
+        const bool trace = alive && (bounce < P.bounce_limit);
+        if (alive && !trace) { valid = 0; end_path = true; }               // loop exhausted, :38 (Q7)
+
+        float t_hit = 0.f;
+        int tri = bvh_closest_hit<COUNT>(P.nodes, P.tris, P.root_ref, ro, rd, my_stack, t_hit, trace, n_iters, n_tri, n_box);
+
+        if (trace) {
+            n_rays++;
+            if (tri < 0) {
+                // miss: r.mul_spectrum(background) and stop (rendering.cu:24-27)
+#pragma unroll
+                for (int k = 0; k < kWavelengths; k++) {
+                    if ((uint32_t)k < valid) {
+                        int off; float w;
+                        interp_coords(wl[k], off, w);
+                        pw[k] *= interp_pair(s_bg[off], w);
+                    }
+                }
+                end_path = true;
+            } else {
+                // rebuild the hit record from (t, triangle): tri::hit tail (tri.cu:36-39) + set_face_normal
+                const float4 ta = P.tris[3 * tri + 0];
+                const float4 tc = P.tris[3 * tri + 2];
+                const V3 n_geo = mk(ta.x, ta.y, ta.z);
+                const V3 hp = ro + t_hit * rd;                                          // ray::at, ray.cuh:31-34
+                const bool front_face = dot(rd, n_geo) < 0;                            // hit_record.cuh:41
+                const V3 n = front_face ? n_geo : -n_geo;
+                const uint32_t mat = __float_as_uint(tc.z) >> 8;
+                const float4 mp0 = P.mat_par[2 * mat + 0];
+                const float4 mp1 = P.mat_par[2 * mat + 1];
+                const uint32_t mtype = __float_as_uint(mp0.x);
+
+                // material::scatter (materials/material.cu:55-100)
+                V3 scatter_direction = mk(0.f, 0.f, 0.f);
+                float eps_sign = 1.0f;
+                bool did_scatter = true;
+                const V3 unit_in = unit_vector(rd);
+                if (mtype == 4u) {                                                      // EMISSIVE, :83-86
+                    did_scatter = false;
+                } else if (mtype == 2u) {                                               // DIELECTRIC, :73-80
+                    float ir = sellmeier_index(mp0.z, mp0.w, mp1.x, mp1.y, mp1.z, mp1.w, wl[0]);
+                    // refraction_scatter, :102-136
+                    float refraction_ratio = front_face ? (1.0f / ir) : ir;
+                    float cos_theta = fminf(dot(-unit_in, n), 1.0f);
+                    float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+                    bool cannot_refract = refraction_ratio * sin_theta > 1.0f;
+                    if (!cannot_refract)                                                // short-circuit ||, :114
+                        cannot_refract = reflectance(cos_theta, refraction_ratio) > rng_uniform(rs);
+                    if (cannot_refract) {
+                        scatter_direction = reflect(unit_in, n);
+                    } else {
+                        scatter_direction = refract(unit_in, n, refraction_ratio);
+                        eps_sign = -1.0f;
+                        valid = 1;                                                      // :78-79 (Q6)
+                    }
+                } else {
+                    // METALLIC (:64-71) and LAMBERTIAN/default (:88-92) both start with random_unit_vector
+                    const V3 ruv = unit_vector(random_in_unit_sphere(rs));             // vec3.cuh:221-227
+                    if (mtype == 1u) {
+                        V3 reflected = reflect(unit_in, n);                            // reflection_scatter, :22-37
+                        scatter_direction = reflected + mp0.y * ruv;
+                        did_scatter = dot(scatter_direction, n) > 0;
+                        if (!did_scatter) valid = 0;
+                    } else {
+                        scatter_direction = n + ruv;                                   // lambertian_scatter, :8-19
+                        if (near_zero(scatter_direction)) scatter_direction = n;
+                    }
+                }
+                // r_in.mul_spectrum(spectral_distribution) (:95), after valid_wavelengths was updated (Q8)
+                const float2 *sd = P.mat_sd + (size_t)mat * 96u;
+#pragma unroll
+                for (int k = 0; k < kWavelengths; k++) {
+                    if ((uint32_t)k < valid) {
+                        int off; float w;
+                        interp_coords(wl[k], off, w);
+                        pw[k] *= interp_pair(sd[off], w);
+                    }
+                }
+                ro = hp + (eps_sign * kEpsilon) * n;                                    // :96 (Q9)
+                rd = scatter_direction;                                                 // :97
+                if (!did_scatter) {
+                    end_path = true;
+                } else {
+                    bounce++;
+                }
+            }
+        }
+
+        // ---- path end: pixel_color += dev_spectrum_to_XYZ(...) (rendering.cu:227, color.cu:88-104) ------
+        if (alive && end_path) {
+            const float delta_lambda = (kLambdaMax - kLambdaMin) / (float)kWavelengths;
+            float x = 0.0f, y = 0.0f, z = 0.0f;
+#pragma unroll
+            for (int k = 0; k < kWavelengths; k++) {
+                if ((uint32_t)k < valid) {
+                    int off; float w;
+                    interp_coords(wl[k], off, w);
+                    const float4 r0 = s_cmf[off], r1 = s_cmf[off + 1];
+                    const float power = pw[k];
+                    x += ((1.0f - w) * r0.x + w * r1.x) * power * delta_lambda;
+                    y += ((1.0f - w) * r0.y + w * r1.y) * power * delta_lambda;
+                    z += ((1.0f - w) * r0.z + w * r1.z) * power * delta_lambda;
+                }
+            }
+            acc = acc + mk(x, y, z);
+            need_path = true;
+        }
+    }
+
+    // ---- epilogue: store RNG state (rendering.cu:232) and save_to_fb (rendering.cu:140-149) --------------
+    if (in_image) {
+        P.rng[0 * (size_t)P.n_lanes + idx] = rs.d;
+        P.rng[1 * (size_t)P.n_lanes + idx] = rs.v0;
+        P.rng[2 * (size_t)P.n_lanes + idx] = rs.v1;
+        P.rng[3 * (size_t)P.n_lanes + idx] = rs.v2;
+        P.rng[4 * (size_t)P.n_lanes + idx] = rs.v3;
+        P.rng[5 * (size_t)P.n_lanes + idx] = rs.v4;
+    }
+    {
+        // pixel_color / float(spp) -> (1/spp) * v ; XYZ_to_sRGB (color.cu:35-41, vec3.cuh:80-91)
+        const float inv_spp = 1.0f / (float)P.spp;
+        const V3 c = inv_spp * acc;
+        const float r_lin = (3.2404542f * c.x) + (-1.5371385f * c.y) + (-0.4985314f * c.z);
+        const float g_lin = (-0.9692660f * c.x) + (1.8760108f * c.y) + (0.0415560f * c.z);
+        const float b_lin = (0.0556434f * c.x) + (-0.2040259f * c.y) + (1.0572252f * c.z);
+        const float r = correct_channel(r_lin), g = correct_channel(g_lin), b = correct_channel(b_lin);
+        float *o = P.tile_out + (size_t)blockIdx.x * (kTilePlanes * kTileLanes) + lane;
+        // expand_sRGB (color.cu:43-49): float(int(v*255.99f))  (Q15)
+        o[0 * kTileLanes] = in_image ? (float)(int)(r * 255.99f) : 0.f;
+        o[1 * kTileLanes] = in_image ? (float)(int)(g * 255.99f) : 0.f;
+        o[2 * kTileLanes] = in_image ? (float)(int)(b * 255.99f) : 0.f;
+        o[3 * kTileLanes] = in_image ? r : 0.f;
+        o[4 * kTileLanes] = in_image ? g : 0.f;
+        o[5 * kTileLanes] = in_image ? b : 0.f;
+        o[6 * kTileLanes] = acc.x;
+        o[7 * kTileLanes] = acc.y;
+        o[8 * kTileLanes] = acc.z;
+    }
+    {
+        uint32_t r = wave_sum(n_rays);
+        if (lane == 0 && r) atomicAdd(&P.counters[0], (unsigned long long)r);
+        if (COUNT) {
+            uint32_t a = wave_sum(n_iters), b = wave_sum(n_tri), c = wave_sum(n_box);
+            if (lane == 0) {
+                atomicAdd(&P.counters[1], (unsigned long long)a);
+                atomicAdd(&P.counters[2], (unsigned long long)b);
+                atomicAdd(&P.counters[3], (unsigned long long)c);
+            }
+        }
+    }
+}
+
+// Gathered compact tiles -> block-linear planar framebuffer (rendering.cu:146-148 layout).
+__global__ __launch_bounds__(64) void scatter_tiles_kernel(const ScatterParams P) {
+    const uint32_t tile = blockIdx.x;
+    const uint32_t lane = threadIdx.x;
+    if (tile >= P.n_tiles) return;
+    const uint32_t tile_x = tile % P.tiles_x, tile_y = tile / P.tiles_x;
+    const uint32_t i = tile_x * 8u + (lane & 7u), j = tile_y * 8u + (lane >> 3);
+    if (i >= P.width || j >= P.height || i / P.tx >= P.bx || j / P.ty >= P.by) return;
+    const uint32_t idx = block_linear_idx(i, j, P.tx, P.ty, P.bx);
+    const uint32_t rank = tile % P.world, local = tile / P.world;
+    const float *src = P.gathered + ((size_t)rank * P.tiles_padded + local) * (kTilePlanes * kTileLanes) + lane;
+#pragma unroll
+    for (int p = 0; p < kTilePlanes; p++) P.fb[p][idx] = src[p * kTileLanes];
+}
+
+// render_manager::update_fb's un-swizzle (render_manager.cuh:68-142), one thread per block-linear index.
+__global__ void unswizzle_kernel(const float *r, const float *g, const float *b, float *dr, float *dg, float *db, uint32_t tx,
+                                 uint32_t ty, uint32_t bx, uint32_t by, uint32_t n_cols, uint32_t n_rows, uint32_t offx,
+                                 uint32_t offy, uint32_t image_width, uint32_t image_height) {
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t block_size = tx * ty;
+    if (idx >= block_size * bx * by) return;
+    const uint32_t blk = idx / block_size, thread_idx = idx % block_size;
+    const uint32_t block_x = blk % bx, block_y = blk / bx;
+    uint32_t fb_x = tx * block_x + thread_idx % tx;
+    uint32_t fb_y = ty * block_y + thread_idx / tx;
+    if (fb_x < n_cols && fb_y < n_rows) {
+        fb_x += offx; fb_y += offy;
+        if (fb_x < image_width && fb_y < image_height) {
+            const size_t o = (size_t)fb_y * image_width + fb_x;
+            dr[o] = r[idx]; dg[o] = g[idx]; db[o] = b[idx];
+        }
+    }
+}
+
+// bvh::hit for explicit rays (KAT entry point)
+__global__ __launch_bounds__(64) void trace_rays_kernel(const RenderParams P, const float *rays, uint32_t n, float *out) {
+    extern __shared__ float4 lds4[];
+    uint32_t *s_stack = reinterpret_cast<uint32_t *>(lds4);
+    const uint32_t lane = threadIdx.x;
+    const uint32_t k = blockIdx.x * 64u + lane;
+    const bool active = k < n;
+    V3 o = mk(0, 0, 0), d = mk(0, 0, 1);
+    if (active) { o = mk(rays[6 * k + 0], rays[6 * k + 1], rays[6 * k + 2]); d = mk(rays[6 * k + 3], rays[6 * k + 4], rays[6 * k + 5]); }
+    uint32_t a = 0, b = 0, c = 0;
+    float t = 0.f;
+    int tri = bvh_closest_hit<false>(P.nodes, P.tris, P.root_ref, o, d, s_stack + lane, t, active, a, b, c);
+    if (active) {
+        float ff = 0.f, mat = 0.f;
+        if (tri >= 0) {
+            const float4 ta = P.tris[3 * tri + 0];
+            const float4 tc = P.tris[3 * tri + 2];
+            ff = dot(d, mk(ta.x, ta.y, ta.z)) < 0 ? 1.f : 0.f;
+            mat = (float)(__float_as_uint(tc.z) >> 8);
+        }
+        out[4 * k + 0] = tri >= 0 ? t : 0.f;
+        out[4 * k + 1] = (float)tri;
+        out[4 * k + 2] = ff;
+        out[4 * k + 3] = mat;
+    }
+}
+
+// Primitive-op sweep: proves device + - * / sqrt fmin fmax casts and srt_powf are bit-identical to the host.
+__global__ void op_sweep_kernel(int which, const float *a, const float *b, uint32_t n, float *out) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const float x = a[k], y = b[k];
+    float r;
+    switch (which) {
+    case 0: r = x + y; break;
+    case 1: r = x - y; break;
+    case 2: r = x * y; break;
+    case 3: r = x / y; break;
+    case 4: r = sqrtf(x); break;
+    case 5: r = fminf(x, y); break;
+    case 6: r = fmaxf(x, y); break;
+    case 7: r = (float)(int)x; break;
+    case 8: r = dev_powf(x, y); break;
+    case 9: r = 1.0f / x; break;
+    case 10: r = fabsf(x); break;
+    case 11: r = x * y + y; break;                      // must NOT contract into an fma
+    case 12: r = (float)__float_as_uint(x); break;      // u32 -> f32 conversion (RNG uniform mapping)
+    case 13: r = x * x + y * y + x * y; break;          // dot-style chain, left associated
+    default: r = 0.f;
+    }
+    out[k] = r;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------------
+hipError_t launch_init_rng(uint32_t *rng, uint32_t n_lanes, uint64_t seed, hipStream_t st) {
+    if (n_lanes == 0) return hipSuccess;
+    hipLaunchKernelGGL(init_rng_kernel, dim3((n_lanes + 255) / 256), dim3(256), 0, st, rng, n_lanes, seed);
+    return hipGetLastError();
+}
+
+hipError_t launch_render(const RenderParams &p, uint32_t tiles_local, bool count_traversal, hipStream_t st) {
+    if (tiles_local == 0) return hipSuccess;
+    const size_t lds = render_lds_bytes(p.stack_depth);
+    if (count_traversal) hipLaunchKernelGGL(render_kernel<true>, dim3(tiles_local), dim3(64), lds, st, p);
+    else hipLaunchKernelGGL(render_kernel<false>, dim3(tiles_local), dim3(64), lds, st, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_scatter(const ScatterParams &p, hipStream_t st) {
+    if (p.n_tiles == 0) return hipSuccess;
+    hipLaunchKernelGGL(scatter_tiles_kernel, dim3(p.n_tiles), dim3(64), 0, st, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_unswizzle(const float *const src[3], float *const dst[3], uint32_t tx, uint32_t ty, uint32_t bx, uint32_t by,
+                            uint32_t n_cols, uint32_t n_rows, uint32_t offx, uint32_t offy, uint32_t image_width,
+                            uint32_t image_height, hipStream_t st) {
+    const uint32_t n = tx * ty * bx * by;
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(unswizzle_kernel, dim3((n + 255) / 256), dim3(256), 0, st, src[0], src[1], src[2], dst[0], dst[1], dst[2],
+                       tx, ty, bx, by, n_cols, n_rows, offx, offy, image_width, image_height);
+    return hipGetLastError();
+}
+
+hipError_t launch_trace(const RenderParams &p, const float *rays, size_t n, float *out, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    const size_t lds = (size_t)(p.stack_depth < 1 ? 1 : p.stack_depth) * 64 * 4;
+    hipLaunchKernelGGL(trace_rays_kernel, dim3((uint32_t)((n + 63) / 64)), dim3(64), lds, st, p, rays, (uint32_t)n, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_op_sweep(int which, const float *a, const float *b, size_t n, float *out, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(op_sweep_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, which, a, b, (uint32_t)n, out);
+    return hipGetLastError();
+}
+
+}  // namespace srt

@@ -1,0 +1,134 @@
+"""Device renderer handle (srt_ctx): the `renderer` / render_manager::step pair of the reference
+(rendering/rendering.cuh:39-155, rendering/render_manager.cu:3-66) over the C-ABI.  All compute happens in
+libsrt_hip.so on the GPU; this module only moves pointers."""
+import ctypes as C
+
+import numpy as np
+
+from . import binding as B
+
+DEFAULT_TX, DEFAULT_TY = 28, 16   # render_manager.cu:93-94
+
+
+def reference_grid(chunk_w, chunk_h, tx=DEFAULT_TX, ty=DEFAULT_TY):
+    """blocks = (w/28+1, h/16+1), render_manager.cu:96"""
+    return chunk_w // tx + 1, chunk_h // ty + 1
+
+
+class Renderer:
+    def __init__(self, device=0):
+        h = C.c_void_p()
+        B.check(B.lib().srt_create(int(device), C.byref(h)))
+        self._h = h
+        self.device = device
+        self.geom = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            B.lib().srt_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, code):
+        return B.check(code, self._h)
+
+    def upload_scene(self, scene):
+        self._ck(B.lib().srt_upload_scene(self._h, scene.handle))
+
+    def set_camera(self, cam):
+        self._ck(B.lib().srt_set_camera(self._h, C.byref(cam)))
+
+    def init_device_params(self, chunk_w, chunk_h, spp, bounce_limit, seed=1984, tx=DEFAULT_TX, ty=DEFAULT_TY, bx=None, by=None):
+        if bx is None or by is None:
+            bx, by = reference_grid(chunk_w, chunk_h, tx, ty)
+        self._ck(B.lib().srt_init_device_params(self._h, tx, ty, bx, by, chunk_w, chunk_h, spp, bounce_limit, seed))
+        self.geom = dict(tx=tx, ty=ty, bx=bx, by=by, chunk_w=chunk_w, chunk_h=chunk_h, n_lanes=tx * ty * bx * by)
+
+    def set_partition(self, rank, world):
+        self._ck(B.lib().srt_set_partition(self._h, rank, world))
+
+    def set_count_traversal(self, on):
+        self._ck(B.lib().srt_set_count_traversal(self._h, 1 if on else 0))
+
+    def render_chunk(self, width, height, offx=0, offy=0, stream=None):
+        self._ck(B.lib().srt_render_chunk(self._h, width, height, offx, offy, C.c_void_p(stream or 0)))
+
+    def synchronize(self):
+        self._ck(B.lib().srt_synchronize(self._h))
+
+    def tile_buffer(self):
+        ptr, n, tl, tp = C.c_void_p(), C.c_size_t(), C.c_uint32(), C.c_uint32()
+        self._ck(B.lib().srt_tile_buffer(self._h, C.byref(ptr), C.byref(n), C.byref(tl), C.byref(tp)))
+        return ptr.value, n.value, tl.value, tp.value
+
+    def scatter_tiles(self, gathered_ptr=None, stream=None):
+        self._ck(B.lib().srt_scatter_tiles(self._h, C.c_void_p(gathered_ptr or 0), C.c_void_p(stream or 0)))
+
+    def dev_fb(self):
+        r, g, b, n = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_size_t()
+        self._ck(B.lib().srt_dev_fb(self._h, C.byref(r), C.byref(g), C.byref(b), C.byref(n)))
+        return r.value, g.value, b.value, n.value
+
+    def read_fb(self):
+        n = self.geom["n_lanes"]
+        r, g, b = (np.zeros(n, np.float32) for _ in range(3))
+        self._ck(B.lib().srt_read_fb(self._h, B.fptr(r), B.fptr(g), B.fptr(b)))
+        return r, g, b
+
+    def read_fb_aux(self, which):
+        n = self.geom["n_lanes"]
+        r, g, b = (np.zeros(n, np.float32) for _ in range(3))
+        self._ck(B.lib().srt_read_fb_aux(self._h, which, B.fptr(r), B.fptr(g), B.fptr(b)))
+        return r, g, b
+
+    def read_fb_rowmajor(self, image_width, image_height, into=None):
+        if into is None:
+            into = tuple(np.zeros(image_width * image_height, np.float32) for _ in range(3))
+        r, g, b = into
+        self._ck(B.lib().srt_read_fb_rowmajor(self._h, B.fptr(r), B.fptr(g), B.fptr(b), image_width, image_height))
+        return r, g, b
+
+    def stats(self):
+        st = B.Stats()
+        self._ck(B.lib().srt_get_stats(self._h, C.byref(st)))
+        return {k: getattr(st, k) for k in ("rays", "paths", "node_visits", "tri_tests", "box_tests")}
+
+    def last_kernel_ms(self):
+        ms = C.c_float()
+        self._ck(B.lib().srt_last_kernel_ms(self._h, C.byref(ms)))
+        return ms.value
+
+    def trace_rays(self, rays):
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
+        out = np.zeros((rays.shape[0], 4), np.float32)
+        self._ck(B.lib().srt_trace_rays(self._h, B.fptr(rays), rays.shape[0], B.fptr(out)))
+        return out
+
+    def op_sweep(self, which, a, b):
+        a = np.ascontiguousarray(a, np.float32); b = np.ascontiguousarray(b, np.float32)
+        out = np.zeros_like(a)
+        self._ck(B.lib().srt_device_op_sweep(self._h, which, B.fptr(a), B.fptr(b), a.size, B.fptr(out)))
+        return out
+
+
+def render_image(scene, cam, width, height, spp, bounce_limit, seed=1984, device=0, count_traversal=False, renderer=None):
+    """Whole-image single-chunk render on one GPU (the reference's default configuration, Q13).
+    Returns dict with block-linear planes, row-major quantised planes, stats and kernel ms."""
+    r = renderer or Renderer(device)
+    r.upload_scene(scene)
+    r.set_camera(cam)
+    r.init_device_params(width, height, spp, bounce_limit, seed)
+    r.set_partition(0, 1)
+    r.set_count_traversal(count_traversal)
+    r.render_chunk(width, height, 0, 0)
+    r.scatter_tiles()
+    out = dict(fb=r.read_fb(), lin=r.read_fb_aux(1), xyz=r.read_fb_aux(2), rowmajor=r.read_fb_rowmajor(width, height),
+               stats=r.stats(), kernel_ms=r.last_kernel_ms(), geom=dict(r.geom))
+    if renderer is None:
+        r.close()
+    return out

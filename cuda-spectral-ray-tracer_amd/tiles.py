@@ -1,0 +1,63 @@
+"""Tile partition + framebuffer gather for the multi-GPU path (one process per GPU, torch.distributed).
+
+The image chunk is cut into 8x8-pixel tiles (one wave each).  Rank r of W renders tiles t with t % W == r:
+interleaving at tile granularity balances the sky / geometry cost gradient, and because every pixel's RNG
+seed is 1984 + its block-linear index (rendering/rendering.cu:137) the image is bit-identical for any W.
+The only exchange step is ONE gather of the compact tile buffers to rank 0 (RCCL over xGMI when the
+tensors are on GPUs; gloo in the CPU tests), followed by a scatter into the block-linear planar framebuffer.
+"""
+import torch
+import torch.distributed as dist
+
+TILE = 8
+PLANES = 9
+LANES = 64
+
+
+def tile_geometry(width, height, tx, ty, bx, by, world):
+    cover_w, cover_h = min(width, tx * bx), min(height, ty * by)
+    tiles_x, tiles_y = (cover_w + TILE - 1) // TILE, (cover_h + TILE - 1) // TILE
+    n_tiles = tiles_x * tiles_y
+    return dict(tiles_x=tiles_x, tiles_y=tiles_y, n_tiles=n_tiles, tiles_padded=(n_tiles + world - 1) // world,
+                cover_w=cover_w, cover_h=cover_h)
+
+
+def local_tile_ids(n_tiles, rank, world):
+    return list(range(rank, n_tiles, world))
+
+
+def gather_tiles(local, rank, world, group=None, dst=0):
+    """local: [tiles_padded, PLANES, LANES] float32 tensor (same shape on every rank).
+    Returns [world, tiles_padded, PLANES, LANES] on rank `dst`, None elsewhere.  One collective."""
+    if world == 1:
+        return local.unsqueeze(0)
+    if rank == dst:
+        out = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
+        dist.gather(local, list(out.unbind(0)), dst=dst, group=group)
+        return out
+    dist.gather(local, None, dst=dst, group=group)
+    return None
+
+
+def block_linear_index(i, j, tx, ty, bx):
+    """idx = ty*28+tx + 448*(by*gridDim.x+bx), rendering/rendering.cu:156-165 (i, j chunk-relative tensors)."""
+    gbx, gby = i // tx, j // ty
+    return (j - gby * ty) * tx + (i - gbx * tx) + tx * ty * (gby * bx + gbx)
+
+
+def scatter_tiles_torch(gathered, width, height, tx, ty, bx, by, world):
+    """Pure-torch scatter of gathered tiles into PLANES block-linear planes (used by the CPU/gloo tests; the GPU
+    path uses srt_scatter_tiles).  gathered: [world, tiles_padded, PLANES, LANES]."""
+    g = tile_geometry(width, height, tx, ty, bx, by, world)
+    n_lanes = tx * ty * bx * by
+    fb = torch.zeros((PLANES, n_lanes), dtype=gathered.dtype, device=gathered.device)
+    t = torch.arange(g["n_tiles"], device=gathered.device)
+    lane = torch.arange(LANES, device=gathered.device)
+    i = (t % g["tiles_x"])[:, None] * TILE + (lane % TILE)[None, :]
+    j = (t // g["tiles_x"])[:, None] * TILE + (lane // TILE)[None, :]
+    ok = (i < g["cover_w"]) & (j < g["cover_h"])
+    idx = block_linear_index(i, j, tx, ty, bx)
+    src = gathered[t % world, t // world]            # [n_tiles, PLANES, LANES]
+    for p in range(PLANES):
+        fb[p][idx[ok]] = src[:, p, :][ok]
+    return fb

@@ -1,0 +1,200 @@
+/*
+ * srt_c_api.h -- C-ABI of the MI355X-native spectral path-tracing hot path.
+ *
+ * This is the drop-in boundary for PieSil/CUDA-spectral-ray-tracer's render path.  The reference has
+ * no FFI layer: the path sits behind the host classes `renderer` (rendering/rendering.cuh:39-155) and
+ * `render_manager` (rendering/render_manager.cuh:37-224) and consumes device-heap objects built by
+ * `scene_manager` (scene/scene.cuh:103-176).  Each entry point below names the reference interface it
+ * replaces.  Plain pointers and sizes only; no C++/torch types.  All functions return 0 on success and
+ * a negative srt_status on failure (never exit(): the reference's checkCudaErrors -> exit(99),
+ * utils/cuda_utility.cu:8-18, is deliberately not reproduced); srt_last_error() gives the message.
+ *
+ * Host-side objects (srt_scene) need no GPU.  A device context (srt_ctx) needs a gfx950 device and
+ * fails loudly without one -- there is no CPU fallback behind this API.
+ */
+#ifndef SRT_C_API_H
+#define SRT_C_API_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SRT_API __attribute__((visibility("default")))
+
+#define SRT_N_CIE_SAMPLES 95      /* utils/cie_const.cuh:8 */
+#define SRT_N_RAY_WAVELENGTHS 7   /* ray/ray.cuh:12 */
+#define SRT_DEFAULT_SEED 1984u    /* rendering/rendering.cu:137, scene/scene.cu:14 */
+#define SRT_DEFAULT_TX 28u        /* rendering/render_manager.cu:93-94 */
+#define SRT_DEFAULT_TY 16u
+
+typedef enum {
+    SRT_OK = 0,
+    SRT_ERR_INVALID = -1,      /* bad argument / call order (reference: message on cerr, call ignored) */
+    SRT_ERR_NO_DEVICE = -2,    /* no gfx950 device / HIP runtime error at context creation */
+    SRT_ERR_HIP = -3,          /* HIP runtime error (reference: checkCudaErrors -> exit(99)) */
+    SRT_ERR_BVH = -4,          /* BVH build failed (reference: scene.cu:413-416 "Error building BVH") */
+    SRT_ERR_UNSUPPORTED = -5,  /* e.g. non-grey sRGB colour without the (missing) rgb2spec table */
+    SRT_ERR_NOMEM = -6
+} srt_status;
+
+/* material_type ids, materials/material.cuh:16-22 */
+enum { SRT_MAT_LAMBERTIAN = 0, SRT_MAT_METALLIC = 1, SRT_MAT_DIELECTRIC = 2, SRT_MAT_EMISSIVE = 4, SRT_MAT_NO_MAT = 6 };
+/* AAPlane, primitives/tri.cuh:8-13 */
+enum { SRT_AAP_NONE = 0, SRT_AAP_XY = 1, SRT_AAP_YZ = 2, SRT_AAP_XZ = 3 };
+/* scene ids: the reference's three (io/params.h:15-19) plus this build's synthetic benchmark scenes */
+enum { SRT_SCENE_CORNELL = 0, SRT_SCENE_PRISM = 1, SRT_SCENE_TRIS = 2, SRT_SCENE_RANDOM_SPHERES = 100, SRT_SCENE_MESH100K = 101 };
+/* BVH builders */
+enum { SRT_BVH_REFERENCE = 0,  /* bit-faithful reference topology, bvh/bvh.cu:206-346 (x/y-only median split, Q14) */
+       SRT_BVH_SAH = 1 };      /* this build's binned-SAH builder (same node semantics, better tree) */
+
+/* Raw triangle as scene construction leaves it, before tri::init (primitives/tri.cu:47-84).
+ * aa_plane is the value the member holds BEFORE init runs (sticky); NONE for a fresh tri. */
+typedef struct { float v0[3], v1[3], v2[3]; uint32_t mat_index; uint32_t aa_plane; } srt_tri_in;
+
+/* Same field order and size (428 B) as `material`, materials/material.cuh:140-148. */
+typedef struct {
+    float col[3];
+    float reflection_fuzz;
+    uint32_t material_type;
+    float spectral_distribution[SRT_N_CIE_SAMPLES];
+    float emission_power;
+    float sellmeier_B[3];
+    float sellmeier_C[3];
+} srt_material;
+
+/* Same field order and size (84 B) as `camera_data`, rendering/rendering.cuh:28-36. */
+typedef struct {
+    uint32_t width, height;
+    float pixel_delta_u[3], pixel_delta_v[3], pixel00_loc[3];
+    float defocus_angle;
+    float camera_center[3], defocus_disk_u[3], defocus_disk_v[3];
+} srt_camera_data;
+
+/* Per-launch counters: a ray = one closest-hit query (bvh::hit call). */
+typedef struct {
+    uint64_t rays, paths;
+    uint64_t node_visits;   /* traversal iterations = paired-child records fetched (V) */
+    uint64_t tri_tests;     /* leaf (triangle) tests (T) */
+    uint64_t box_tests;
+    uint64_t reserved[3];
+} srt_stats;
+
+typedef struct srt_scene srt_scene;   /* host-side flattened scene (replaces scene_manager's device heap) */
+typedef struct srt_ctx srt_ctx;       /* one GPU's renderer (replaces `renderer`, rendering.cuh:39-155) */
+
+/* ---------------------------------------------------------------------------------------------------
+ * Host side: scene inputs (no GPU).  Replaces scene_manager::init_world (scene/scene.cu:349-428),
+ * create_world_kernel (:22-54) and create_bvh_kernel (:9-20).
+ * ------------------------------------------------------------------------------------------------- */
+SRT_API const char *srt_version(void);
+
+/* camera::initialize, rendering/camera.cu:7-58 (camera_builder::getCamera, camera_builder.cuh:57-61). */
+SRT_API int srt_camera_init(int image_width, int image_height, float vfov, const float lookfrom[3], const float lookat[3],
+                            const float vup[3], float defocus_angle, float focus_dist, srt_camera_data *out);
+
+/* Empty scene / one of the built-in scenes (scene/scene.cu:73-226; synthetic ids documented in DESIGN.md).
+ * `seed` drives the synthetic scenes' layout PRNG; ignored for the reference scenes. */
+SRT_API srt_scene *srt_scene_create(void);
+SRT_API srt_scene *srt_scene_builtin(int scene_id, uint64_t seed);
+SRT_API void srt_scene_destroy(srt_scene *s);
+/* Default camera of a built-in scene (scene/scene.cu:259-320) for the given image size. */
+SRT_API int srt_scene_default_camera(const srt_scene *s, int image_width, int image_height, srt_camera_data *out);
+
+/* Scene construction.  srt_scene_set_* replace the whole list. */
+SRT_API int srt_scene_set_triangles(srt_scene *s, const srt_tri_in *tris, size_t n);
+SRT_API int srt_scene_set_materials(srt_scene *s, const srt_material *mats, size_t m);
+SRT_API int srt_scene_set_background(srt_scene *s, const float spectrum[SRT_N_CIE_SAMPLES]);
+SRT_API size_t srt_scene_tri_count(const srt_scene *s);
+SRT_API size_t srt_scene_material_count(const srt_scene *s);
+SRT_API int srt_scene_get_triangles(const srt_scene *s, srt_tri_in *out);       /* raw inputs, original order */
+SRT_API int srt_scene_get_materials(const srt_scene *s, srt_material *out);
+SRT_API int srt_scene_get_background(const srt_scene *s, float out[SRT_N_CIE_SAMPLES]);
+/* tri::init results, 12 floats per triangle: normal(3) D clockwise aa_plane bbox(xmin xmax ymin ymax zmin zmax). */
+SRT_API int srt_scene_get_tri_records(const srt_scene *s, float *out);
+
+/* material::compute_spectral_distr (materials/material.cuh:71-84) for table-free colours (grey, white,
+ * light, glass); SRT_ERR_UNSUPPORTED for non-grey sRGB (utils/srgb_to_spectrum.cu is absent upstream). */
+SRT_API int srt_material_bake(srt_material *m);
+/* dev_srgb_to_spectrum / dev_srgb_to_illuminance_spectrum evaluated from explicit sigmoid coefficients
+ * (color/color_to_spectrum.cuh:173-186,204-219): value = [scale * D65n(l)] * sigmoid(c[2] l^2 + c[1] l + c[0]). */
+SRT_API int srt_bake_sigmoid_spectrum(const float coeffs[3], float scale, int times_d65, float out[SRT_N_CIE_SAMPLES]);
+/* host srgb_to_illuminance_spectrum for the background (rendering/rendering.cu:324), grey colours only. */
+SRT_API int srt_background_spectrum(const float rgb[3], float out[SRT_N_CIE_SAMPLES]);
+
+/* BVH: `mode` SRT_BVH_REFERENCE reproduces create_bvh_kernel (fresh XORWOW(seed), bvh/bvh.cu:206-346);
+ * SRT_BVH_SAH is this build's builder.  Either way the node semantics are the reference's: binary tree,
+ * one triangle per leaf, leaf box = padded triangle box, internal box = union of children (Q22). */
+SRT_API int srt_scene_build_bvh(srt_scene *s, int mode, uint64_t seed);
+SRT_API size_t srt_scene_node_count(const srt_scene *s);
+SRT_API int srt_scene_bvh_depth(const srt_scene *s);
+/* Pre-order dump (same convention as the oracle): left/right = pre-order ranks or -1, prim = original
+ * triangle index for leaves else -1, boxes = 6 floats per node (xmin xmax ymin ymax zmin zmax). */
+SRT_API int srt_scene_get_bvh(const srt_scene *s, int32_t *left, int32_t *right, int32_t *prim, float *boxes);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Device side.  Replaces `renderer` (rendering/rendering.cuh:39-155) + the device half of
+ * render_manager::step (rendering/render_manager.cu:3-66).
+ * ------------------------------------------------------------------------------------------------- */
+/* renderer ctor + hipSetDevice.  Fails with SRT_ERR_NO_DEVICE when no GPU is usable. */
+SRT_API int srt_create(int device, srt_ctx **out);
+SRT_API void srt_destroy(srt_ctx *ctx);
+SRT_API const char *srt_last_error(const srt_ctx *ctx);   /* ctx may be NULL: last global error */
+
+/* Uploads triangles, paired-child BVH records, material spectra and background to HBM
+ * (replaces the device-heap world behind bvh** / material*, scene.cuh:163-170).  The BVH must be built. */
+SRT_API int srt_upload_scene(srt_ctx *ctx, const srt_scene *s);
+/* renderer::assign_cam_data, rendering/rendering.cu:237-242 */
+SRT_API int srt_set_camera(srt_ctx *ctx, const srt_camera_data *cam);
+/* renderer::init_device_params (rendering/rendering.cu:279-357) + render_manager::init_renderer
+ * (render_manager.cu:121-133): threads (tx,ty), grid (bx,by), chunk size, spp, bounce limit, RNG base seed.
+ * Allocates the block-linear planar framebuffer and seeds the per-lane RNG states (init_random_states,
+ * rendering.cu:120-138: XORWOW(seed + idx)).  spp / bounce_limit are narrowed to 16 bit like the reference (Q17). */
+SRT_API int srt_init_device_params(srt_ctx *ctx, uint32_t tx, uint32_t ty, uint32_t bx, uint32_t by, uint32_t chunk_w,
+                                   uint32_t chunk_h, uint32_t spp, uint32_t bounce_limit, uint64_t seed);
+/* Multi-GPU split: this context renders tiles t with t % world == rank (8x8-pixel tiles of the chunk grid).
+ * Seeds depend on the pixel only, so any split gives a bit-identical image.  Default rank 0, world 1. */
+SRT_API int srt_set_partition(srt_ctx *ctx, uint32_t rank, uint32_t world);
+
+/* renderer::render(w,h,offx,offy) -> call_render_kernel (rendering.cu:244-277).  Asynchronous on `stream`
+ * (a hipStream_t passed as void*, NULL = default stream); the reference's device-wide sync is srt_synchronize.
+ * Renders this rank's tiles into the context's compact tile buffer. */
+SRT_API int srt_render_chunk(srt_ctx *ctx, uint32_t width, uint32_t height, uint32_t offx, uint32_t offy, void *stream);
+SRT_API int srt_synchronize(srt_ctx *ctx);
+
+/* Compact tile buffer of this rank (device memory, for the RCCL gather): n_tiles_local * 9 * 64 floats,
+ * [tile][plane][lane], planes = quantised r,g,b | unquantised sRGB r,g,b | XYZ sums.  tiles_padded is the
+ * per-rank tile capacity ceil(n_tiles/world) so that every rank's buffer has the same size. */
+SRT_API int srt_tile_buffer(srt_ctx *ctx, void **dev_ptr, size_t *n_floats, uint32_t *tiles_local, uint32_t *tiles_padded);
+/* Scatter gathered tile buffers (device pointer, world * tiles_padded * 9 * 64 floats, rank-major) into this
+ * context's block-linear planar framebuffer (rendering.cu:146-148 layout).  With world == 1 pass the
+ * context's own tile buffer (or NULL to use it). */
+SRT_API int srt_scatter_tiles(srt_ctx *ctx, const void *dev_gathered, void *stream);
+
+/* renderer::getDevFBr/g/b (rendering.cuh:87-97): device pointers to the block-linear planes (tx*bx*ty*by floats). */
+SRT_API int srt_dev_fb(srt_ctx *ctx, void **r, void **g, void **b, size_t *n_floats);
+/* The three cudaMemcpyAsync D2H of render_manager::step (render_manager.cu:41-45): block-linear, grid sized. */
+SRT_API int srt_read_fb(srt_ctx *ctx, float *r, float *g, float *b);
+/* D2H + the un-swizzle of render_manager::update_fb (render_manager.cuh:68-142) done on the device:
+ * writes the last rendered chunk into row-major image planes of width image_width at (offx, offy). */
+SRT_API int srt_read_fb_rowmajor(srt_ctx *ctx, float *r, float *g, float *b, uint32_t image_width, uint32_t image_height);
+/* Parity planes, block-linear: which = 1 unquantised sRGB in [0,1] (value before expand_sRGB), 2 = XYZ sums. */
+SRT_API int srt_read_fb_aux(srt_ctx *ctx, int which, float *p0, float *p1, float *p2);
+
+SRT_API int srt_get_stats(srt_ctx *ctx, srt_stats *out);       /* counters of the last srt_render_chunk */
+SRT_API int srt_set_count_traversal(srt_ctx *ctx, int on);     /* 1: instrumented kernel also counts V / T */
+/* Kernel-only time of the last srt_render_chunk in ms, measured with HIP events on its stream. */
+SRT_API int srt_last_kernel_ms(srt_ctx *ctx, float *ms);
+/* Closest-hit query for explicit rays (bvh::hit, bvh/bvh.cu:98-166) -- KAT entry point.
+ * rays: n * 6 floats (origin, direction); out: n * 4 floats (t, tri_index or -1, front_face, mat_index). */
+SRT_API int srt_trace_rays(srt_ctx *ctx, const float *rays, size_t n, float *out);
+/* Device arithmetic self-test: evaluates op `which` on n operand pairs on the GPU (see DESIGN.md "primitive-op
+ * sweep"); used to prove the device's + - * / sqrt fmin cast and srt_powf bits equal the host's. */
+SRT_API int srt_device_op_sweep(srt_ctx *ctx, int which, const float *a, const float *b, size_t n, float *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SRT_C_API_H */
