@@ -46,11 +46,13 @@ SRT_HD float srt_powf(float xf, float yf) {
     p = p * s + 1.0 / 3.0;
     p = p * s + 1.0;
     double lg = 2.0 * f * p;
-    double t = y * ((double)e * 0.6931471805599453 + lg);
-    double kd = __builtin_floor(t * 1.4426950408889634 + 0.5);
+    double A = y * (double)e;                 // exact: 24-bit * 11-bit
+    double z = y * lg;
+    double kd = __builtin_floor((A + z * 1.4426950408889634) + 0.5);
     if (kd > 1000.0) return __builtin_inff();
     if (kd < -1000.0) return 0.0f;
-    double r = (t - kd * 0.693147180369123816490) - kd * 1.90821492927058770002e-10;
+    double dd = A - kd;                        // exact
+    double r = (dd * 0.693147180369123816490 + z) + dd * 1.90821492927058770002e-10;
     double q = 1.0 / 87178291200.0;
     q = q * r + 1.0 / 6227020800.0;
     q = q * r + 1.0 / 479001600.0;

@@ -214,7 +214,8 @@ ORC_API int orc_random_int(int min, int max, orc_rng *s) {
  * Call sites in the reference: materials/material.cu:48, color/color.cu:19.
  * Spec (all fp64, no contraction):  x = m*2^e with m in (sqrt(.5), sqrt(2)];
  *   f=(m-1)/(m+1); s=f*f; log(m) = 2 f (1 + s/3 + ... + s^12/25)  (Horner);
- *   t = y*(e*LN2 + log m); k = floor(t*LOG2E + .5); r = (t - k*LN2_HI) - k*LN2_LO;
+ *   A = y*e (exact); z = y*log m; k = floor((A + z*LOG2E) + .5); d = A - k (exact);
+ *   r = (d*LN2_HI + z) + d*LN2_LO;
  *   exp(r) = sum_{n<=14} r^n/n! (Horner); result = (float)(exp(r) * 2^k).
  * ---------------------------------------------------------------------------------------- */
 ORC_API float orc_powf(float xf, float yf) {
@@ -247,11 +248,13 @@ ORC_API float orc_powf(float xf, float yf) {
     p = p * s + 1.0 / 3.0;
     p = p * s + 1.0;
     double lg = 2.0 * f * p;
-    double t = y * ((double)e * 0.6931471805599453 + lg);
-    double kd = floor(t * 1.4426950408889634 + 0.5);
+    double A = y * (double)e;                 /* exact: 24-bit * 11-bit */
+    double z = y * lg;
+    double kd = floor((A + z * 1.4426950408889634) + 0.5);
     if (kd > 1000.0) return INFINITY;
     if (kd < -1000.0) return 0.0f;
-    double r = (t - kd * 0.693147180369123816490) - kd * 1.90821492927058770002e-10;
+    double dd = A - kd;                        /* exact */
+    double r = (dd * 0.693147180369123816490 + z) + dd * 1.90821492927058770002e-10;
     double q = 1.0 / 87178291200.0;
     q = q * r + 1.0 / 6227020800.0;
     q = q * r + 1.0 / 479001600.0;

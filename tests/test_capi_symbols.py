@@ -1,0 +1,47 @@
+"""The C-ABI library loads and exports every symbol include/srt_c_api.h declares (no compute calls, no GPU)."""
+import ctypes as C
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "srt_c_api.h")).read()
+    return sorted(set(re.findall(r"SRT_API\s+[\w\s\*]+?\b(srt_\w+)\s*\(", src)))
+
+
+def test_header_and_binding_agree(srt):
+    names = declared_symbols()
+    assert len(names) >= 40
+    assert sorted(srt.binding.PROTOTYPES) == names
+
+
+def test_library_exports_everything(srt):
+    L = C.CDLL(srt.binding.LIB_PATH)
+    for name in declared_symbols():
+        assert getattr(L, name) is not None
+    assert b"gfx950" in srt.binding.lib().srt_version()
+
+
+def test_no_gpu_fails_loudly(srt):
+    """Without a usable GPU the device context cannot be created and nothing falls back to the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        return
+    h = C.c_void_p()
+    rc = srt.binding.lib().srt_create(0, C.byref(h))
+    assert rc == -2 and not h.value
+    assert b"no CPU fallback" in srt.binding.lib().srt_last_error(None)
+
+
+def test_product_does_not_reference_the_oracle():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may touch oracle/."""
+    pkg = os.path.join(ROOT, "cuda-spectral-ray-tracer_amd")
+    for dirpath, _, files in os.walk(pkg):
+        if "_build" in dirpath:
+            continue
+        for f in files:
+            if f.endswith((".py", ".cpp", ".h", ".hip", "Makefile")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "oracle" not in text.lower().replace("the cpu oracle", "").replace("cpu oracle", ""), os.path.join(dirpath, f)

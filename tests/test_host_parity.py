@@ -1,0 +1,128 @@
+"""Host-side product code (libsrt_hip.so, no GPU needed) against the oracle and the SURVEY known answers:
+scene construction, tri::init records, both BVH builders, camera, spectra baking.  CPU only."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+from helpers import bits, oracle_scene_for
+
+G = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "survey_kats.json")))
+
+
+@pytest.mark.parametrize("sid,ntris,nmats,nnodes", [(1, 20, 3, 39), (0, 42, 7, 83), (2, 42, 9, 83)])
+def test_reference_scenes(srt, orc, sid, ntris, nmats, nnodes):
+    s = srt.Scene.builtin(sid).build_bvh(srt.BVH_REFERENCE, 1984)
+    assert (s.n_tris, s.n_materials, s.n_nodes) == (ntris, nmats, nnodes)     # scene.cu:228-257, 2N-1 nodes
+    osc = oracle_scene_for(orc, s, 0)
+    assert np.array_equal(bits(osc.tri_records()), bits(s.tri_records()))     # tri::init products, bit for bit
+    for a, b in zip(osc.bvh(), s.bvh()):                                      # reference-topology builder
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_prism_known_answers(srt, orc):
+    s = srt.Scene.builtin(srt.SCENE_PRISM).build_bvh(srt.BVH_REFERENCE, 1984)
+    k = G["prism_tri4"]
+    rec = s.tri_records()[k["list_index"]]
+    assert np.allclose(rec[:3], k["normal_6digits"], rtol=0, atol=1e-6) and abs(rec[3] - k["D_6digits"]) < 1e-3
+    # rotated side quads keep the axis plane of their construction-time normal (Q12)
+    assert [int(r[5]) for r in s.tri_records()[12:20]] == [1, 1, 2, 2, 0, 0, 0, 0]
+    osc = oracle_scene_for(orc, s, 0)
+    k = G["prism_ray"]
+    hit, out = osc.trace(k["o"], k["d"])
+    assert hit == 1 and np.float32(out[0]) == np.float32(k["t"])
+    assert [np.float32(v) for v in out[1:4]] == [np.float32(v) for v in k["p"]]
+    assert int(out[7]) == k["front_face"] and int(out[8]) == k["mat"]
+
+
+def test_prism_statistics_match_survey_probe(srt, orc):
+    s = srt.Scene.builtin(srt.SCENE_PRISM).build_bvh(srt.BVH_REFERENCE, 1984)
+    osc = oracle_scene_for(orc, s, 0)
+    k = G["prism_stats_96x96_32spp_depth16"]
+    st = osc.render(s.default_camera(96, 96), 96, 96, 32, 16)["stats"]
+    assert abs(st["rays"] / st["paths"] - k["rays_per_path"]) < 0.05
+    assert abs(st["trav_iters"] / st["rays"] - k["iters_per_ray"]) < 0.15
+    assert abs(st["box_tests"] / st["rays"] - k["box_per_ray"]) < 0.15
+    assert abs(st["tri_tests"] / st["rays"] - k["tri_per_ray"]) < 0.15
+    assert st["max_stack"] <= k["max_stack_le"]
+
+
+def test_materials_and_background(srt, orc):
+    s = srt.Scene.builtin(srt.SCENE_CORNELL)
+    mats = s.materials()
+    assert C.sizeof(srt.Material) == 428
+    light, white, glass, metal = mats[4], mats[3], mats[2], mats[5]
+    k = G["light_1_1_1_power5_baked"]
+    assert [np.float32(light.spectral_distribution[i]) for i in k["indices"]] == [np.float32(v) for v in k["values"]]
+    assert set(white.spectral_distribution) == {1.0} and set(glass.spectral_distribution) == {1.0}
+    assert set(metal.spectral_distribution) == {0.5}
+    assert list(glass.sellmeier_C) == list(glass.sellmeier_B)                 # Q1
+    assert not s.background().any()
+    # product baking == oracle baking for every table-free material
+    for m in (light, white, glass, metal):
+        om = orc.Material.from_buffer_copy(bytes(m))
+        for i in range(95):
+            om.spectral_distribution[i] = -1.0
+        assert orc.lib().orc_material_bake(C.byref(om)) == 1
+        assert bytes(om) == bytes(m)
+    red = srt.Material.from_buffer_copy(bytes(mats[0]))
+    assert srt.binding.lib().srt_material_bake(C.byref(red)) == -5   # SRT_ERR_UNSUPPORTED
+    co = np.array([0.25, -0.003, 1.5e-6], np.float32)
+    a, b = np.zeros(95, np.float32), np.zeros(95, np.float32)
+    for scale, d65 in ((1.0, 0), (25.0, 1)):
+        srt.binding.lib().srt_bake_sigmoid_spectrum(srt.binding.fptr(co), scale, d65, srt.binding.fptr(a))
+        orc.lib().orc_bake_sigmoid_spectrum(orc.fptr(co), scale, d65, orc.fptr(b))
+        assert np.array_equal(bits(a), bits(b))
+
+
+def test_camera_matches_oracle(srt, orc):
+    for (w, h, vfov, lf, la, da, fd) in [(256, 256, 40.0, (278, 278, -800), (278, 278, 0), 0.0, 10.0),
+                                         (1920, 1080, 20.0, (13, 2, 3), (0, 0, 0), 0.6, 10.0),
+                                         (37, 91, 75.0, (1, -2, 3.5), (0.25, 0, -1), 2.0, 3.0)]:
+        cam = srt.camera_init(w, h, vfov, lf, la, (0, 1, 0), da, fd)
+        oc = orc.CameraData()
+        orc.lib().orc_camera_init(w, h, vfov, orc.f3(lf), orc.f3(la), orc.f3((0, 1, 0)), da, fd, C.byref(oc))
+        assert bytes(cam) == bytes(oc)
+    k = G["camera_cornell_256"]
+    cam = srt.Scene.builtin(srt.SCENE_CORNELL).default_camera(256, 256)
+    assert [np.float32(v) for v in cam.pixel00_loc] == [np.float32(v) for v in k["p00"]]
+
+
+@pytest.mark.parametrize("sid", [100, 101])
+def test_sah_tree_is_a_valid_reference_style_bvh(srt, orc, sid):
+    s = srt.Scene.builtin(sid, 0).build_bvh(srt.BVH_SAH)
+    n = s.n_tris
+    assert s.n_nodes == 2 * n - 1
+    left, right, prim, boxes = s.bvh()
+    leaves = prim[prim >= 0]
+    assert np.array_equal(np.sort(leaves), np.arange(n))                      # every triangle in exactly one leaf
+    inner = np.nonzero(prim < 0)[0]
+    assert np.all(left[inner] > 0) and np.all(right[inner] > 0)
+    # internal box = union of children, leaf box = padded tri box (Q22): the oracle recomputes them independently
+    osc = oracle_scene_for(orc, s, 1)
+    for a, b in zip(osc.bvh(), s.bvh()):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert s.bvh_depth <= 64
+    if sid == 100:
+        assert 4000 < n < 6000 and s.n_materials > 400                        # RS-488: ~500 objects, ~4.8 k tris
+    else:
+        assert n > 100000
+
+
+def test_error_paths(srt):
+    L = srt.binding.lib()
+    assert L.srt_scene_builtin(12345, 0) is None
+    assert b"unknown" in L.srt_last_error(None)
+    s = srt.Scene(L.srt_scene_create())
+    with pytest.raises(srt.SrtError):
+        s.build_bvh(srt.BVH_REFERENCE)                                        # empty scene: "Error building BVH"
+    with pytest.raises(srt.SrtError):
+        s.build_bvh(7)
+    # one-triangle scene: the root is a leaf (bvh.cu:114-119)
+    t = (srt.TriIn * 1)()
+    t[0].v0[:] = [0, 0, 0]; t[0].v1[:] = [1, 0, 0]; t[0].v2[:] = [0, 1, 0]
+    m = (srt.Material * 1)()
+    s1 = srt.Scene.from_arrays(t, m, np.zeros(95, np.float32)).build_bvh(srt.BVH_REFERENCE)
+    assert s1.n_nodes == 1 and s1.bvh()[2][0] == 0
