@@ -872,13 +872,16 @@ static void render_block(render_job *J, uint32_t block_idx) {
 }
 
 static void *render_worker(void *arg) {
-    render_job *J = (render_job *)arg;
+    /* work on a stack copy: the per-ray counters must not share cache lines between threads */
+    render_job local = *(render_job *)arg;
+    render_job *J = &local;
     for (;;) {
         uint32_t k = __sync_fetch_and_add(J->next_block, 1u);
         uint32_t b = J->block_lo + k * J->block_stride;
         if (b >= J->block_hi) break;
         render_block(J, b);
     }
+    ((render_job *)arg)->stats = local.stats;
     return NULL;
 }
 
