@@ -1,0 +1,271 @@
+// host_api.hpp -- C++ host mirror of the reference's interface for the render path, header-only, on top of the
+// C-ABI (include/srt_c_api.h).  Same class and method names, argument meaning and "print and ignore" error
+// behaviour as the reference host classes, so that main.cpp-style drivers keep working:
+//
+//   camera / camera_builder      rendering/camera.cuh:6-104, rendering/camera_builder.cuh:13-71
+//   frame_buffer / image_channels rendering/frame_buffer.cuh:6-71
+//   scene_manager                scene/scene.cuh:103-176   (device-heap world -> flattened srt_scene)
+//   renderer                     rendering/rendering.cuh:39-155
+//   render_manager               rendering/render_manager.cuh:37-224, rendering/render_manager.cu
+//
+// Differences forced by the boundary: the first two constructor arguments of renderer / render_manager
+// (bvh** dev_bvh, material* dev_mat_list) become one `const srt_scene*` (a device-heap pointer tree is not
+// portable); dim3 becomes a plain struct; CUDA errors become return codes instead of exit(99).
+#pragma once
+#include <stdint.h>
+
+#include <cmath>
+#include <iostream>
+#include <semaphore>
+#include <string>
+#include <thread>
+
+#include "../../include/srt_c_api.h"
+
+namespace srt_host {
+
+typedef unsigned int uint;
+struct dim3 { uint x = 1, y = 1, z = 1; dim3() {} dim3(uint x_, uint y_ = 1, uint z_ = 1) : x(x_), y(y_), z(z_) {} };
+struct vec3 { float e[3] = {0.f, 0.f, 0.f}; vec3() {} vec3(float a, float b, float c) : e{a, b, c} {} float operator[](int i) const { return e[i]; } };
+using point3 = vec3;
+using color = vec3;
+
+// rendering/camera.cuh:6-104
+class camera {
+public:
+    camera() {}
+    camera(float ar, int w, int h, float _vfov, point3 _lookfrom, point3 _lookat, vec3 _vup, float _da, float _fd, color bg)
+        : aspect_ratio(ar), image_width(w), image_height(h), background(bg) {
+        srt_camera_init(w, h, _vfov, _lookfrom.e, _lookat.e, _vup.e, _da, _fd, &data);   // camera::initialize, camera.cu:7-58
+        num_pixels = (uint)(w * h);
+    }
+    const int &getImageWidth() const { return image_width; }
+    const int &getImageHeight() const { return image_height; }
+    const uint &getNumPixels() const { return num_pixels; }
+    vec3 getCenter() const { return v(data.camera_center); }
+    vec3 getPixel00Loc() const { return v(data.pixel00_loc); }
+    vec3 getPixelDeltaU() const { return v(data.pixel_delta_u); }
+    vec3 getPixelDeltaV() const { return v(data.pixel_delta_v); }
+    float getDefocusAngle() const { return data.defocus_angle; }
+    vec3 getDefocusDiskU() const { return v(data.defocus_disk_u); }
+    vec3 getDefocusDiskV() const { return v(data.defocus_disk_v); }
+    const color &getBackground() const { return background; }
+    const srt_camera_data &getCameraData() const { return data; }   // camera_data, rendering.cuh:19-37
+private:
+    static vec3 v(const float *p) { return vec3(p[0], p[1], p[2]); }
+    float aspect_ratio = 1.f;
+    int image_width = 0, image_height = 0;
+    uint num_pixels = 0;
+    color background;
+    srt_camera_data data{};
+};
+
+// rendering/camera_builder.cuh:13-71 (image size comes from the caller instead of the param_manager singleton)
+class camera_builder {
+public:
+    camera_builder setVfov(float v) { vfov = v; return *this; }
+    camera_builder setLookfrom(point3 p) { lookfrom = p; return *this; }
+    camera_builder setLookat(point3 p) { lookat = p; return *this; }
+    camera_builder setVup(vec3 p) { vup = p; return *this; }
+    camera_builder setDefocusAngle(float a) { defocus_angle = a; return *this; }
+    camera_builder setFocusDist(float d) { focus_dist = d; return *this; }
+    camera_builder setBackground(color c) { background = c; return *this; }
+    camera_builder setImageSize(int xres, int yres) { width = xres; height = yres; return *this; }
+    camera getCamera() const { return camera((float)width / (float)height, width, height, vfov, lookfrom, lookat, vup, defocus_angle, focus_dist, background); }
+private:
+    float vfov = 90.0f;
+    point3 lookfrom = point3(0, 0, -1), lookat = point3(0, 0, 0);
+    vec3 vup = vec3(0, 1, 0);
+    float defocus_angle = 0, focus_dist = 10;
+    color background = color(0, 0, 0);
+    int width = 600, height = 600;   // io/params.h:204-222 defaults (xres 600, AR 1)
+};
+
+// rendering/frame_buffer.cuh:6-44: planar float RGB, row-major, values already 0..255
+class frame_buffer {
+public:
+    explicit frame_buffer(size_t img_size) : channel_size(img_size) { r = new float[img_size](); g = new float[img_size](); b = new float[img_size](); }
+    ~frame_buffer() { delete[] r; delete[] g; delete[] b; }
+    frame_buffer(const frame_buffer &) = delete;
+    size_t single_channel_byte_size() const { return channel_size * sizeof(float); }
+    void split_channels(unsigned char *const _r, unsigned char *const _g, unsigned char *const _b) const {
+        for (size_t i = 0; i < channel_size; i++) { _r[i] = (unsigned char)r[i]; _g[i] = (unsigned char)g[i]; _b[i] = (unsigned char)b[i]; }
+    }
+    size_t channel_size;
+    float *r, *g, *b;
+};
+
+// rendering/frame_buffer.cuh:46-71
+struct image_channels {
+    explicit image_channels(frame_buffer &fb) : n(fb.channel_size) { r = new unsigned char[n]; g = new unsigned char[n]; b = new unsigned char[n]; fb.split_channels(r, g, b); }
+    image_channels &operator=(const frame_buffer &fb) { fb.split_channels(r, g, b); return *this; }
+    ~image_channels() { delete[] r; delete[] g; delete[] b; }
+    size_t n;
+    unsigned char *r, *g, *b;
+};
+
+// scene/scene.cuh:103-176: owns the world; getWorld()/getMaterials() collapse into getScene()
+class scene_manager {
+public:
+    explicit scene_manager(int scene_id, int xres, int yres, int bvh_mode = SRT_BVH_REFERENCE, uint64_t seed = SRT_DEFAULT_SEED) {
+        s = srt_scene_builtin(scene_id, 0);
+        if (!s) { res_msg = srt_last_error(nullptr); return; }
+        if (srt_scene_build_bvh(s, bvh_mode, seed) != SRT_OK) { res_msg = "Error building BVH\n"; return; }   // scene.cu:413-416
+        srt_camera_data cd;
+        srt_scene_default_camera(s, xres, yres, &cd);
+        cam_data = cd; xr = xres; yr = yres;
+        world_inited = true; res_msg = "World created";
+    }
+    ~scene_manager() { srt_scene_destroy(s); }
+    scene_manager(const scene_manager &) = delete;
+    bool isWorldInited() const { return world_inited; }
+    const std::string &getResultMsg() const { return res_msg; }
+    const srt_scene *getScene() const { return s; }
+    const srt_camera_data &getCameraData() const { return cam_data; }
+    int getXres() const { return xr; }
+    int getYres() const { return yr; }
+    size_t getWorldSize() const { return srt_scene_tri_count(s); }
+    size_t getNumMaterials() const { return srt_scene_material_count(s); }
+private:
+    srt_scene *s = nullptr;
+    srt_camera_data cam_data{};
+    int xr = 0, yr = 0;
+    bool world_inited = false;
+    std::string res_msg;
+};
+
+// rendering/rendering.cuh:39-155
+class renderer {
+public:
+    renderer() {}
+    renderer(const srt_scene *scene, uint _samples_per_pixel, const srt_camera_data &cam, uint _bounce_limit, int device = 0)
+        : samples_per_pixel(_samples_per_pixel), bounce_limit(_bounce_limit) {
+        if (srt_create(device, &ctx) != SRT_OK) { std::cerr << "renderer: " << srt_last_error(nullptr) << std::endl; return; }
+        if (srt_upload_scene(ctx, scene) != SRT_OK || srt_set_camera(ctx, &cam) != SRT_OK) std::cerr << "renderer: " << srt_last_error(ctx) << std::endl;
+    }
+    ~renderer() { if (ctx) srt_destroy(ctx); }
+    renderer(const renderer &) = delete;
+    renderer &operator=(renderer &&o) noexcept { if (ctx) srt_destroy(ctx); ctx = o.ctx; o.ctx = nullptr; samples_per_pixel = o.samples_per_pixel; bounce_limit = o.bounce_limit;
+                                                 max_chunk_width = o.max_chunk_width; max_chunk_height = o.max_chunk_height; device_inited = o.device_inited; return *this; }
+    void init_device_params(dim3 _threads, dim3 _blocks, uint _max_chunk_width, uint _max_chunk_height) {   // rendering.cu:279-357
+        threads = _threads; blocks = _blocks; max_chunk_width = _max_chunk_width; max_chunk_height = _max_chunk_height;
+        device_inited = ctx && srt_init_device_params(ctx, threads.x, threads.y, blocks.x, blocks.y, max_chunk_width, max_chunk_height, samples_per_pixel,
+                                                      bounce_limit, SRT_DEFAULT_SEED) == SRT_OK;
+        if (!device_inited) std::cerr << "renderer: " << srt_last_error(ctx) << std::endl;
+    }
+    void render(uint offset_x, uint offset_y) { call_render_kernel(max_chunk_width, max_chunk_height, offset_x, offset_y); }     // rendering.cuh:57-61
+    void render(uint width, uint height, uint offset_x, uint offset_y) { call_render_kernel(width, height, offset_x, offset_y); }   // :63-66
+    uint getMaxChunkWidth() const { return max_chunk_width; }
+    uint getMaxChunkHeight() const { return max_chunk_height; }
+    const float *getDevFBr() const { return plane(0); }   // rendering.cuh:87-97 (device pointers)
+    const float *getDevFBg() const { return plane(1); }
+    const float *getDevFBb() const { return plane(2); }
+    srt_ctx *getContext() const { return ctx; }
+private:
+    void call_render_kernel(uint width, uint height, uint offset_x, uint offset_y) {   // rendering.cu:244-277
+        if (!device_inited) { std::cerr << "Device parameters were not initialized, render aborted" << std::endl; return; }
+        if (srt_render_chunk(ctx, width, height, offset_x, offset_y, nullptr) != SRT_OK || srt_scatter_tiles(ctx, nullptr, nullptr) != SRT_OK ||
+            srt_synchronize(ctx) != SRT_OK)
+            std::cerr << "renderer: " << srt_last_error(ctx) << std::endl;
+    }
+    const float *plane(int k) const { void *p[3] = {nullptr, nullptr, nullptr}; size_t n = 0; if (ctx) srt_dev_fb(ctx, &p[0], &p[1], &p[2], &n); return (const float *)p[k]; }
+    srt_ctx *ctx = nullptr;
+    uint samples_per_pixel = 0, bounce_limit = 0;
+    uint max_chunk_width = 0, max_chunk_height = 0;
+    dim3 blocks, threads;
+    bool device_inited = false;
+};
+
+// rendering/render_manager.cuh:9-35
+struct render_step_data {
+    render_step_data() : empty(1), full(0) {}
+    uint starting_offset_x = 0, starting_offset_y = 0, chunk_width = 0, chunk_height = 0;
+    std::counting_semaphore<1> empty, full;   // utils/multithread.cuh:3
+    bool is_last = false;
+};
+
+// rendering/render_manager.cuh:37-224 + render_manager.cu.  The staging copy + CPU un-swizzle of the reference
+// (three grid-sized D2H copies, then a 2M-iteration div/mod loop) is replaced by one device un-swizzle kernel
+// writing straight into the row-major frame_buffer planes (srt_read_fb_rowmajor).
+class render_manager {
+public:
+    render_manager(const srt_scene *_scene, camera *_cam, frame_buffer *_fb) {
+        if (_scene != nullptr && _cam != nullptr && _fb != nullptr) {
+            scene = _scene; cam = _cam; fb = _fb;
+            image_width = (uint)cam->getImageWidth(); image_height = (uint)cam->getImageHeight();
+            scene_inited = true;
+        }
+    }
+    ~render_manager() { end_render(); }
+
+    void init_renderer(uint bounce_limit, uint samples_per_pixel, int device = 0) {   // render_manager.cu:121-133
+        if (scene_inited) { r = renderer(scene, samples_per_pixel, cam->getCameraData(), bounce_limit, device); renderer_inited = true; }
+        else std::cerr << "Scene not yet initialized" << std::endl;
+    }
+    void init_device_params(dim3 _threads, dim3 _blocks, uint _chunk_width, uint _chunk_height) {   // render_manager.cu:68-89
+        if (!renderer_inited) { std::cerr << "Initialize renderer before assigning device parameters" << std::endl; return; }
+        threads = _threads; blocks = _blocks; chunk_width = _chunk_width; chunk_height = _chunk_height;
+        x_chunks = (uint)std::ceil(float(image_width) / float(chunk_width));
+        uint y_chunks = (uint)std::ceil(float(image_height) / float(chunk_height));
+        n_iterations = x_chunks * y_chunks;
+        r.init_device_params(threads, blocks, chunk_width, chunk_height);
+        device_inited = true;
+    }
+    void init_device_params(uint _chunk_width, uint _chunk_height) {   // render_manager.cu:91-102
+        if (!renderer_inited) { std::cerr << "Init renderer before assigning device parameters" << std::endl; return; }
+        const uint tx = 28, ty = 16;
+        init_device_params(dim3(tx, ty), dim3(_chunk_width / tx + 1, _chunk_height / ty + 1), _chunk_width, _chunk_height);
+    }
+    void init_device_params() { init_device_params(image_width, image_height); }   // render_manager.cu:104-119
+
+    bool step() {   // render_manager.cu:3-66
+        const uint endpoint_x = chunk_width + offset_x, endpoint_y = chunk_height + offset_y;
+        last_chunk_width = endpoint_x > image_width ? chunk_width - (endpoint_x - image_width) : chunk_width;
+        last_chunk_height = endpoint_y > image_height ? chunk_height - (endpoint_y - image_height) : chunk_height;
+        render_step_data *rd = &render_data_container[next_write_render_data_index];
+        next_write_render_data_index = (next_write_render_data_index + 1) % 2;
+        rd->empty.acquire();
+        rd->chunk_width = last_chunk_width; rd->chunk_height = last_chunk_height;
+        rd->starting_offset_x = offset_x; rd->starting_offset_y = offset_y;
+        r.render(last_chunk_width, last_chunk_height, offset_x, offset_y);
+        // the device framebuffer holds this chunk until the next render(): un-swizzle it into fb now
+        srt_read_fb_rowmajor(r.getContext(), fb->r, fb->g, fb->b, image_width, image_height);
+        bool last_step = false;
+        i++;
+        if (i == n_iterations) { rd->is_last = true; last_step = true; }
+        rd->full.release();
+        offset_x = (i % x_chunks) * chunk_width;
+        offset_y = (i / x_chunks) * chunk_height;
+        return !last_step;
+    }
+    bool update_fb() {   // render_manager.cuh:68-142: hand-off only, pixels are already in fb
+        render_step_data *rd = &render_data_container[next_read_render_data_index];
+        next_read_render_data_index = (next_read_render_data_index + 1) % 2;
+        rd->full.acquire();
+        const bool last_read = rd->is_last;
+        rd->empty.release();
+        return !last_read;
+    }
+    bool isDone() const { return done; }
+    uint getImWidth() const { return image_width; }
+    uint getImHeight() const { return image_height; }
+    bool isReadyToRender() const { return device_inited && i < n_iterations; }
+    void render_cycle() { end_render(); done = false; render_worker = std::thread(&render_manager::render_loop, this); worker_started = true; }   // :160-166
+    void end_render() { if (worker_started) { render_worker.join(); worker_started = false; } }                                                // :168-173
+private:
+    void render_loop() { while (step()) {} done = true; }
+    const srt_scene *scene = nullptr;
+    camera *cam = nullptr;
+    frame_buffer *fb = nullptr;
+    uint image_width = 0, image_height = 0;
+    bool scene_inited = false, renderer_inited = false, device_inited = false, worker_started = false, done = true;
+    renderer r;
+    render_step_data render_data_container[2];
+    size_t next_write_render_data_index = 0, next_read_render_data_index = 0;
+    uint i = 0, chunk_width = 0, chunk_height = 0, n_iterations = 0, x_chunks = 1;
+    uint offset_x = 0, offset_y = 0, last_chunk_width = 0, last_chunk_height = 0;
+    std::thread render_worker;
+    dim3 threads, blocks;
+};
+
+}  // namespace srt_host
