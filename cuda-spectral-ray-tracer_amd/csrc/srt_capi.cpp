@@ -1,6 +1,7 @@
 // srt_capi.cpp -- device half of the C-ABI: one srt_ctx = one GPU's renderer
 // (replaces `renderer`, rendering/rendering.cuh:39-155, and the device half of render_manager::step).
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -34,7 +35,13 @@ struct srt_ctx {
     float *d_fb = nullptr;          // 9 block-linear planes of n_lanes floats
     float *d_tiles = nullptr;       // compact tile buffer
     size_t tiles_capacity = 0;      // floats
-    unsigned long long *d_counters = nullptr;
+    unsigned long long *d_counters = nullptr;     // [kCounters] statistics + 1 word pixel-queue head behind them
+    int n_cu = 256;
+    uint32_t shade_threshold = 4, waves_per_cu = 0;    // tuning knobs (env SRT_SHADE_THRESHOLD / SRT_WAVES_PER_CU)
+    uint32_t probe_spp = 2;                            // samples of the cost probe (env SRT_PROBE_SPP, 0 = no ordering)
+    uint32_t *d_tile_cost = nullptr, *d_tile_order = nullptr;
+    size_t tile_sched_capacity = 0;
+    float last_probe_ms = 0.f;
     bool count_traversal = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
@@ -100,12 +107,19 @@ int srt_create(int device, srt_ctx **out) {
     if (e != hipSuccess) return hip_fail(nullptr, e, "hipSetDevice");
     srt_ctx *c = new srt_ctx();
     c->device = device;
+    if (const char *ev = getenv("SRT_SHADE_THRESHOLD")) c->shade_threshold = (uint32_t)std::max(1, atoi(ev));
+    if (const char *ev = getenv("SRT_WAVES_PER_CU")) c->waves_per_cu = (uint32_t)std::max(0, atoi(ev));
+    if (const char *ev = getenv("SRT_PROBE_SPP")) c->probe_spp = (uint32_t)std::max(0, atoi(ev));
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->n_cu = prop.multiProcessorCount;
+    }
     std::vector<float> rows(96 * 4);
     cmf_rows(rows.data());
     int rc = upload(c, &c->d_cmf, rows);
     if (rc != SRT_OK) { delete c; return rc; }
-    if ((e = hipMalloc((void **)&c->d_counters, kCounters * sizeof(unsigned long long))) != hipSuccess ||
-        (e = hipMemset(c->d_counters, 0, kCounters * sizeof(unsigned long long))) != hipSuccess ||
+    if ((e = hipMalloc((void **)&c->d_counters, (kCounters + 1) * sizeof(unsigned long long))) != hipSuccess ||
+        (e = hipMemset(c->d_counters, 0, (kCounters + 1) * sizeof(unsigned long long))) != hipSuccess ||
         (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess) {
         int r = hip_fail(nullptr, e, "srt_create");
         srt_destroy(c);
@@ -119,7 +133,7 @@ void srt_destroy(srt_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    void *bufs[] = {c->d_nodes, c->d_tris, c->d_mat_sd, c->d_mat_par, c->d_bg, c->d_cmf, c->d_rng, c->d_fb, c->d_tiles, c->d_counters};
+    void *bufs[] = {c->d_nodes, c->d_tris, c->d_mat_sd, c->d_mat_par, c->d_bg, c->d_cmf, c->d_rng, c->d_fb, c->d_tiles, c->d_counters, c->d_tile_cost, c->d_tile_order};
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -202,13 +216,45 @@ int srt_render_chunk(srt_ctx *c, uint32_t width, uint32_t height, uint32_t offx,
         c->tiles_capacity = need;
     }
     HIP_TRY(c, hipMemsetAsync(c->d_tiles, 0, need * sizeof(float), st));
-    HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, kCounters * sizeof(unsigned long long), st));
+    HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, (kCounters + 1) * sizeof(unsigned long long), st));
     RenderParams p;
     fill_params(c, p);
     p.width = width; p.height = height; p.offx = offx; p.offy = offy;
     p.tiles_x = c->tiles_x; p.tiles_y = c->tiles_y; p.n_tiles = c->n_tiles;
-    HIP_TRY(c, hipEventRecord(c->ev0, st));
-    HIP_TRY(c, launch_render(p, c->tiles_local, c->count_traversal, st));
+    p.tiles_local = c->tiles_local;
+    p.pixel_counter = (uint32_t *)(c->d_counters + kCounters);
+    p.shade_threshold = c->shade_threshold;
+    p.waves_per_cu_override = c->waves_per_cu;
+    // ---- cost-ordered pixel queue --------------------------------------------------------------------------------
+    // A pixel is one sequential RNG stream, so the launch cannot finish before its most expensive pixel does.  A short
+    // probe (probe_spp samples per pixel from a copy of the RNG state, nothing written) measures the traversal cost of
+    // every tile; the queue then hands tiles out in descending cost order (longest-processing-time-first).
+    p.tile_order = nullptr; p.tile_cost = nullptr;
+    const bool ordered = c->probe_spp > 0 && c->spp > 4 * c->probe_spp && c->tiles_local > 1;
+    if (ordered) {
+        if (c->tiles_local > c->tile_sched_capacity) {
+            if (c->d_tile_cost) { (void)hipFree(c->d_tile_cost); c->d_tile_cost = nullptr; }
+            if (c->d_tile_order) { (void)hipFree(c->d_tile_order); c->d_tile_order = nullptr; }
+            HIP_TRY(c, hipMalloc((void **)&c->d_tile_cost, c->tiles_local * sizeof(uint32_t)));
+            HIP_TRY(c, hipMalloc((void **)&c->d_tile_order, c->tiles_local * sizeof(uint32_t)));
+            c->tile_sched_capacity = c->tiles_local;
+        }
+        HIP_TRY(c, hipMemsetAsync(c->d_tile_cost, 0, c->tiles_local * sizeof(uint32_t), st));
+        RenderParams pp = p;
+        pp.spp = c->probe_spp; pp.tile_cost = c->d_tile_cost;
+        HIP_TRY(c, launch_render(pp, (uint32_t)c->n_cu, 2, st));
+        std::vector<uint32_t> cost(c->tiles_local), order(c->tiles_local);
+        HIP_TRY(c, hipMemcpyAsync(cost.data(), c->d_tile_cost, c->tiles_local * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipStreamSynchronize(st));
+        for (uint32_t k = 0; k < c->tiles_local; k++) order[k] = k;
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
+        HIP_TRY(c, hipMemcpyAsync(c->d_tile_order, order.data(), c->tiles_local * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        HIP_TRY(c, hipStreamSynchronize(st));     // `order` is a stack vector
+        HIP_TRY(c, hipMemsetAsync(c->d_counters + kCounters, 0, sizeof(unsigned long long), st));   // rewind the queue head
+        p.tile_order = c->d_tile_order;
+    }
+    HIP_TRY(c, hipEventRecord(c->ev0, st));     // ev0..ev1 bracket the render kernel alone (roofline.achieved)
+    HIP_TRY(c, launch_render(p, (uint32_t)c->n_cu, c->count_traversal ? 1 : 0, st));
     HIP_TRY(c, hipEventRecord(c->ev1, st));
     c->timed = true;
     c->last_paths = 0;   // filled by srt_get_stats from the tile ownership
@@ -306,6 +352,7 @@ int srt_get_stats(srt_ctx *c, srt_stats *out) {
     HIP_TRY(c, hipMemcpy(h, c->d_counters, sizeof(h), hipMemcpyDeviceToHost));
     memset(out, 0, sizeof(*out));
     out->rays = h[0]; out->node_visits = h[1]; out->tri_tests = h[2]; out->box_tests = h[3];
+    for (int k = 0; k < 7; k++) out->util[k] = h[4 + k];
     // paths = spp * pixels owned by this rank
     uint64_t pixels = 0;
     for (uint32_t t = c->rank; t < c->n_tiles; t += c->world) {

@@ -115,10 +115,11 @@ __device__ __forceinline__ void interp_coords(float lambda, int &offset, float &
 // (:21) on a stored (s[k], s[k+1]) pair
 __device__ __forceinline__ float interp_pair(float2 pr, float weight) { return (1.0f - weight) * pr.x + weight * pr.y; }
 
-// init_hero_wavelength (:31-48): hero = u*470+360; next = prev + 470/7 wrapped into [360,830]
-__device__ __forceinline__ void hero_wavelengths(Rng &s, float (&wl)[kWavelengths]) {
-    float step = (kLambdaMax - kLambdaMin) / (float)kWavelengths;
-    float hero = rng_range(s, kLambdaMin, kLambdaMax);
+// init_hero_wavelength (:31-48): hero = u*470+360; next = prev + 470/7 wrapped into [360,830].  The six rotations are a
+// pure function of the hero, so a lane keeps only the hero and re-derives the set (same additions, same bits).
+__device__ __forceinline__ float hero_draw(Rng &s) { return rng_range(s, kLambdaMin, kLambdaMax); }
+__device__ __forceinline__ void hero_expand(float hero, float (&wl)[kWavelengths]) {
+    const float step = (kLambdaMax - kLambdaMin) / (float)kWavelengths;
     wl[0] = hero;
     float lambda = hero;
 #pragma unroll
@@ -214,63 +215,73 @@ __device__ __forceinline__ bool box_test(float lox, float hix, float loy, float 
 // ref >= 0: index of the child's own record (internal child; its box is the one stored here);
 // ref <  0: ~ref is a triangle index (leaf child; leaves are tested directly, bvh.cu:73-76, no box).
 
-// bvh::hit (bvh/bvh.cu:98-166): closest hit, left child then right child, "t <= closest" accepts (Q11),
-// push right iff both internal children are hit.  `stack` is this lane's column of the LDS stack
-// (element k at stack[k*64]).  Returns the hit triangle index or -1; t in `closest`.
+// bvh::hit (bvh/bvh.cu:98-166) as a RESUMABLE per-lane state: closest hit, left child then right child with the
+// updated closest distance, "t <= closest" accepts (Q11), push right iff both internal children are hit.
+// The state lives in registers (node, sp, closest, hit) plus this lane's column of the LDS stack (element k at
+// stack[k*64]), so a wave can interleave traversal steps of some lanes with shading of others.
+struct TravStats {
+    uint32_t n_iters = 0, n_tri = 0, n_box = 0;   // per lane: node records visited, triangle / box tests
+    uint32_t w_iters = 0;                          // wave: traversal steps executed (every lane counts the same)
+    uint32_t w_alive = 0;                          // wave: sum over those steps of lanes that still own work
+};
+
+struct Trav {
+    int node;        // >= 0: record to visit next; < 0: not traversing
+    int sp;          // stack entries in use
+    float c;         // closest_so_far
+    int hit;         // triangle of the closest hit or -1
+};
+
+// Start a closest-hit query (bvh.cu:101-119).  Returns true when the query is already finished (leaf root).
 template <bool COUNT>
-__device__ __forceinline__ int bvh_closest_hit(const float4 *__restrict__ nodes, const float4 *__restrict__ tris,
-                                               int root_ref, V3 o, V3 d, uint32_t *stack, float &closest, bool active,
-                                               uint32_t &n_iters, uint32_t &n_tri, uint32_t &n_box) {
-    float c = kFltMax;
-    int hit_tri = -1;
-    const V3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    int node = -1;
-    if (active) {
-        if (root_ref < 0) {   // root is a leaf (bvh.cu:114-119)
-            float t;
-            if (COUNT) n_tri++;
-            if (tri_test(tris, ~root_ref, o, d, 0.0f, c, t)) { c = t; hit_tri = ~root_ref; }
-        } else {
-            node = root_ref;
-        }
+__device__ __forceinline__ bool trav_begin(Trav &tv, const float4 *__restrict__ tris, int root_ref, V3 o, V3 d, TravStats &ts) {
+    tv.c = kFltMax; tv.hit = -1; tv.sp = 0;
+    if (root_ref < 0) {   // root is a leaf: only one element
+        float t;
+        if (COUNT) ts.n_tri++;
+        if (tri_test(tris, ~root_ref, o, d, 0.0f, tv.c, t)) { tv.c = t; tv.hit = ~root_ref; }
+        tv.node = -1;
+        return true;
     }
-    int sp = 0;
-    while (__ballot(node >= 0) != 0ull) {
-        if (node >= 0) {
-            const float4 q0 = nodes[4 * node + 0];
-            const float4 q1 = nodes[4 * node + 1];
-            const float4 q2 = nodes[4 * node + 2];
-            const float4 q3 = nodes[4 * node + 3];
-            const int lref = (int)__float_as_uint(q3.x), rref = (int)__float_as_uint(q3.y);
-            if (COUNT) n_iters++;
-            bool trav_l = false, trav_r = false;
-            if (lref < 0) {
-                float t;
-                if (COUNT) n_tri++;
-                if (tri_test(tris, ~lref, o, d, 0.0f, c, t)) { c = t; hit_tri = ~lref; }
-            } else {
-                if (COUNT) n_box++;
-                trav_l = box_test(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, inv, 0.0f, c);
-            }
-            if (rref < 0) {
-                float t;
-                if (COUNT) n_tri++;
-                if (tri_test(tris, ~rref, o, d, 0.0f, c, t)) { c = t; hit_tri = ~rref; }
-            } else {
-                if (COUNT) n_box++;
-                trav_r = box_test(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, inv, 0.0f, c);
-            }
-            if (!trav_l && !trav_r) {
-                if (sp == 0) node = -1;
-                else { sp--; node = (int)stack[sp * 64]; }
-            } else {
-                node = trav_l ? lref : rref;
-                if (trav_l && trav_r) { stack[sp * 64] = (uint32_t)rref; sp++; }
-            }
-        }
+    tv.node = root_ref;
+    return false;
+}
+
+// One iteration of the do-while of bvh.cu:120-162 for a lane with tv.node >= 0.
+template <bool COUNT>
+__device__ __forceinline__ void trav_step(Trav &tv, const float4 *__restrict__ nodes, const float4 *__restrict__ tris, V3 o, V3 d,
+                                          V3 inv, uint32_t *stack, TravStats &ts) {
+    const int node = tv.node;
+    const float4 q0 = nodes[4 * node + 0];
+    const float4 q1 = nodes[4 * node + 1];
+    const float4 q2 = nodes[4 * node + 2];
+    const float4 q3 = nodes[4 * node + 3];
+    const int lref = (int)__float_as_uint(q3.x), rref = (int)__float_as_uint(q3.y);
+    if (COUNT) ts.n_iters++;
+    bool trav_l = false, trav_r = false;
+    if (lref < 0) {
+        float t;
+        if (COUNT) ts.n_tri++;
+        if (tri_test(tris, ~lref, o, d, 0.0f, tv.c, t)) { tv.c = t; tv.hit = ~lref; }
+    } else {
+        if (COUNT) ts.n_box++;
+        trav_l = box_test(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, inv, 0.0f, tv.c);
     }
-    closest = c;
-    return hit_tri;
+    if (rref < 0) {
+        float t;
+        if (COUNT) ts.n_tri++;
+        if (tri_test(tris, ~rref, o, d, 0.0f, tv.c, t)) { tv.c = t; tv.hit = ~rref; }
+    } else {
+        if (COUNT) ts.n_box++;
+        trav_r = box_test(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, inv, 0.0f, tv.c);
+    }
+    if (!trav_l && !trav_r) {
+        if (tv.sp == 0) tv.node = -1;
+        else { tv.sp--; tv.node = (int)stack[tv.sp * 64]; }
+    } else {
+        tv.node = trav_l ? lref : rref;
+        if (trav_l && trav_r) { stack[tv.sp * 64] = (uint32_t)rref; tv.sp++; }
+    }
 }
 
 }  // namespace srt

@@ -8,7 +8,7 @@ namespace srt {
 
 constexpr int kTilePlanes = 9;      // quantised rgb | unquantised sRGB | XYZ sums
 constexpr int kTileLanes = 64;      // one wave = one 8x8 pixel tile
-constexpr int kCounters = 8;        // rays, node_visits, tri_tests, box_tests, ...
+constexpr int kCounters = 16;       // rays, node_visits, tri_tests, box_tests, utilisation counters (instrumented build)
 
 // Kernel arguments of one render launch.  All pointers are device pointers.
 struct RenderParams {
@@ -32,6 +32,12 @@ struct RenderParams {
     uint32_t spp, bounce_limit;
     uint32_t tiles_x, tiles_y, n_tiles;   // 8x8 tiles covering the chunk
     uint32_t rank, world;                 // this launch renders tiles t with t % world == rank
+    uint32_t tiles_local;                 // number of tiles this rank owns (pixel queue length / 64)
+    uint32_t *pixel_counter;              // device word, zeroed before the launch: head of the pixel queue
+    uint32_t shade_threshold;             // traversal phase yields to shading once this many lanes wait
+    const uint32_t *tile_order;           // optional: queue slot -> local tile (cost-descending order); null = identity
+    uint32_t *tile_cost;                  // probe mode: per local tile, node records visited by its pixels
+    uint32_t waves_per_cu_override;       // 0 = occupancy API
     // state / outputs
     uint32_t *rng;                        // SoA: 6 planes of n_lanes words, indexed by the block-linear idx
     uint32_t n_lanes;                     // tx*ty*bx*by
@@ -48,7 +54,7 @@ struct ScatterParams {
 };
 
 hipError_t launch_init_rng(uint32_t *rng, uint32_t n_lanes, uint64_t seed, hipStream_t st);
-hipError_t launch_render(const RenderParams &p, uint32_t tiles_local, bool count_traversal, hipStream_t st);
+hipError_t launch_render(const RenderParams &p, uint32_t n_cu, int mode, hipStream_t st);   // mode 0 render, 1 instrumented, 2 cost probe
 hipError_t launch_scatter(const ScatterParams &p, hipStream_t st);
 hipError_t launch_unswizzle(const float *const src[3], float *const dst[3], uint32_t tx, uint32_t ty, uint32_t bx, uint32_t by,
                             uint32_t n_cols, uint32_t n_rows, uint32_t offx, uint32_t offy, uint32_t image_width,

@@ -51,8 +51,23 @@ __global__ void init_rng_kernel(uint32_t *rng, uint32_t n_lanes, uint64_t seed) 
     rng[5 * (size_t)n_lanes + idx] = s.v4;
 }
 
-template <bool COUNT>
+
+// One lane = a small state machine that owns one pixel at a time:
+//   TRAV   (tv.node >= 0)                 walking the BVH for its current ray
+//   RESULT (result_ready)                 traversal finished, hit record waits to be shaded
+//   IDLE   (!have_path)                   needs a new camera ray, or a new pixel when its samples are used up
+//   DEAD                                  pixel queue drained
+// The wave alternates between a traversal phase (all TRAV lanes step together; it ends when P.shade_threshold lanes
+// are waiting, so slow rays do not hold the other lanes hostage) and a shading phase (RESULT / IDLE lanes are
+// shaded, regenerated and re-armed).  Pixels are handed out by one wave-aggregated atomic per refill; which lane
+// renders a pixel has no influence on the result (the RNG stream belongs to the pixel).
+// MODE 0: production; MODE 1: instrumented (counts V / T / utilisation); MODE 2: cost probe -- renders P.spp samples per
+// pixel from a COPY of the RNG state, writes nothing but the per-tile traversal cost used to order the pixel queue.
+template <int MODE>
 __global__ __launch_bounds__(64) void render_kernel(const RenderParams P) {
+    constexpr bool COUNT = (MODE == 1);
+    constexpr bool PROBE = (MODE == 2);
+    constexpr bool ITERS = COUNT || PROBE;
     extern __shared__ float4 lds4[];
     float4 *s_cmf = lds4;
     float2 *s_bg = reinterpret_cast<float2 *>(lds4 + kLdsCmfF4);
@@ -63,47 +78,217 @@ __global__ __launch_bounds__(64) void render_kernel(const RenderParams P) {
     for (uint32_t k = lane; k < kLdsBgF2; k += 64) s_bg[k] = P.bg_sd[k];
     __syncthreads();
 
-    const uint32_t tile = P.rank + P.world * blockIdx.x;
-    const uint32_t tile_x = tile % P.tiles_x, tile_y = tile / P.tiles_x;
-    const uint32_t i = tile_x * 8u + (lane & 7u);          // chunk-relative column (rendering.cu:156)
-    const uint32_t j = tile_y * 8u + (lane >> 3);          // chunk-relative row    (rendering.cu:157)
-    // lanes outside the chunk (or outside the reference grid) never touch RNG or output (rendering.cu:205)
-    bool alive = (tile < P.n_tiles) && (i < P.width) && (j < P.height) && (i / P.tx < P.bx) && (j / P.ty < P.by);
-    const uint32_t idx = alive ? block_linear_idx(i, j, P.tx, P.ty, P.bx) : 0u;
-    const bool in_image = alive;
-
-    Rng rs;
-    rs.d = rs.v0 = rs.v1 = rs.v2 = rs.v3 = rs.v4 = 0u;
-    if (alive) {   // rendering.cu:209
-        rs.d = P.rng[0 * (size_t)P.n_lanes + idx];
-        rs.v0 = P.rng[1 * (size_t)P.n_lanes + idx];
-        rs.v1 = P.rng[2 * (size_t)P.n_lanes + idx];
-        rs.v2 = P.rng[3 * (size_t)P.n_lanes + idx];
-        rs.v3 = P.rng[4 * (size_t)P.n_lanes + idx];
-        rs.v4 = P.rng[5 * (size_t)P.n_lanes + idx];
-    }
-
     const V3 du = mk(P.du[0], P.du[1], P.du[2]), dv = mk(P.dv[0], P.dv[1], P.dv[2]);
-    // pixel_center = p00 + (float)i*du + (float)j*dv with i, j including the chunk offset (rendering.cu:76,221)
-    const V3 pixel_center = (mk(P.p00[0], P.p00[1], P.p00[2]) + (float)(P.offx + i) * du) + (float)(P.offy + j) * dv;
     const V3 cam_center = mk(P.center[0], P.center[1], P.center[2]);
+    const uint32_t n_local_pixels = P.tiles_local * 64u;
+    uint32_t *const my_stack = s_stack + lane;
 
-    V3 acc = mk(0.f, 0.f, 0.f);          // pixel_color (rendering.cu:212)
-    V3 ro = mk(0.f, 0.f, 0.f), rd = mk(0.f, 0.f, 1.f);
-    float wl[kWavelengths], pw[kWavelengths];
+    // ---- lane state ---------------------------------------------------------------------------------------
+    bool dead = false, have_path = false, result_ready = false, have_pixel = false;
+    uint32_t idx = 0;                       // block-linear index of the current pixel (RNG / framebuffer slot)
+    uint32_t out_slot = 0;                  // tile_local * 576 + lane_in_tile
+    V3 pixel_center = mk(0.f, 0.f, 0.f);
+    Rng rs; rs.d = rs.v0 = rs.v1 = rs.v2 = rs.v3 = rs.v4 = 0u;
+    V3 acc = mk(0.f, 0.f, 0.f);             // pixel_color (rendering.cu:212)
+    uint32_t sample = 0, bounce = 0, valid = 0;
+    V3 ro = mk(0.f, 0.f, 0.f), rd = mk(0.f, 0.f, 1.f), inv = mk(0.f, 0.f, 1.f);
+    float hero = kLambdaMin;
+    float pw[kWavelengths];
 #pragma unroll
-    for (int k = 0; k < kWavelengths; k++) { wl[k] = 0.f; pw[k] = 0.f; }
-    uint32_t valid = 0, sample = 0, bounce = 0;
-    bool need_path = true;
-    uint32_t n_rays = 0, n_iters = 0, n_tri = 0, n_box = 0;
-    uint32_t *my_stack = s_stack + lane;
+    for (int k = 0; k < kWavelengths; k++) pw[k] = 0.f;
+    Trav tv; tv.node = -1; tv.sp = 0; tv.c = kFltMax; tv.hit = -1;
+    uint32_t n_rays = 0;
+    TravStats ts;
+    uint32_t cur_tile_local = 0, pixel_iters0 = 0;   // probe only
 
     for (;;) {
-        // ---- path regeneration: renderer::get_ray (rendering.cu:66-87) --------------------------------
-        if (alive && need_path) {
-            if (sample == P.spp) {
-                alive = false;
-            } else {
+        // =========================== shading phase ===========================================================
+        // every lane that is neither traversing nor dead goes through: shade -> path end -> pixel switch ->
+        // camera ray -> start traversal.  The loop repeats only in corner cases (bounce_limit 0, leaf-root BVH).
+        while (__ballot(!dead && tv.node < 0) != 0ull) {
+            bool end_path = false, begin_trav = false;
+
+            // ---- S1: shade a finished closest-hit query: one iteration of ray_bounce's loop (rendering.cu:22-36)
+            if (!dead && tv.node < 0 && result_ready) {
+                result_ready = false;
+                float wl[kWavelengths];
+                hero_expand(hero, wl);
+                if (tv.hit < 0) {
+                    // miss: r.mul_spectrum(background) and stop (rendering.cu:24-27)
+#pragma unroll
+                    for (int k = 0; k < kWavelengths; k++) {
+                        if ((uint32_t)k < valid) {
+                            int off; float w;
+                            interp_coords(wl[k], off, w);
+                            pw[k] *= interp_pair(s_bg[off], w);
+                        }
+                    }
+                    end_path = true;
+                } else {
+                    // rebuild the hit record from (t, triangle): tri::hit tail (tri.cu:36-39) + set_face_normal
+                    const int tri = tv.hit;
+                    const float4 ta = P.tris[3 * tri + 0];
+                    const float4 tc = P.tris[3 * tri + 2];
+                    const V3 n_geo = mk(ta.x, ta.y, ta.z);
+                    const V3 hp = ro + tv.c * rd;                                          // ray::at, ray.cuh:31-34
+                    const bool front_face = dot(rd, n_geo) < 0;                            // hit_record.cuh:41
+                    const V3 n = front_face ? n_geo : -n_geo;
+                    const uint32_t mat = __float_as_uint(tc.z) >> 8;
+                    const float4 mp0 = P.mat_par[2 * mat + 0];
+                    const float4 mp1 = P.mat_par[2 * mat + 1];
+                    const uint32_t mtype = __float_as_uint(mp0.x);
+
+                    // material::scatter (materials/material.cu:55-100)
+                    V3 scatter_direction = mk(0.f, 0.f, 0.f);
+                    float eps_sign = 1.0f;
+                    bool did_scatter = true;
+                    const V3 unit_in = unit_vector(rd);
+                    if (mtype == 4u) {                                                      // EMISSIVE, :83-86
+                        did_scatter = false;
+                    } else if (mtype == 2u) {                                               // DIELECTRIC, :73-80
+                        float ir = sellmeier_index(mp0.z, mp0.w, mp1.x, mp1.y, mp1.z, mp1.w, wl[0]);
+                        // refraction_scatter, :102-136
+                        float refraction_ratio = front_face ? (1.0f / ir) : ir;
+                        float cos_theta = fminf(dot(-unit_in, n), 1.0f);
+                        float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+                        bool cannot_refract = refraction_ratio * sin_theta > 1.0f;
+                        if (!cannot_refract)                                                // short-circuit ||, :114
+                            cannot_refract = reflectance(cos_theta, refraction_ratio) > rng_uniform(rs);
+                        if (cannot_refract) {
+                            scatter_direction = reflect(unit_in, n);
+                        } else {
+                            scatter_direction = refract(unit_in, n, refraction_ratio);
+                            eps_sign = -1.0f;
+                            valid = 1;                                                      // :78-79 (Q6)
+                        }
+                    } else {
+                        // METALLIC (:64-71) and LAMBERTIAN/default (:88-92) both start with random_unit_vector
+                        const V3 ruv = unit_vector(random_in_unit_sphere(rs));             // vec3.cuh:221-227
+                        if (mtype == 1u) {
+                            V3 reflected = reflect(unit_in, n);                            // reflection_scatter, :22-37
+                            scatter_direction = reflected + mp0.y * ruv;
+                            did_scatter = dot(scatter_direction, n) > 0;
+                            if (!did_scatter) valid = 0;
+                        } else {
+                            scatter_direction = n + ruv;                                   // lambertian_scatter, :8-19
+                            if (near_zero(scatter_direction)) scatter_direction = n;
+                        }
+                    }
+                    // r_in.mul_spectrum(spectral_distribution) (:95), after valid_wavelengths was updated (Q8)
+                    const float2 *sd = P.mat_sd + (size_t)mat * 96u;
+#pragma unroll
+                    for (int k = 0; k < kWavelengths; k++) {
+                        if ((uint32_t)k < valid) {
+                            int off; float w;
+                            interp_coords(wl[k], off, w);
+                            pw[k] *= interp_pair(sd[off], w);
+                        }
+                    }
+                    ro = hp + (eps_sign * kEpsilon) * n;                                    // :96 (Q9)
+                    rd = scatter_direction;                                                 // :97
+                    if (!did_scatter) {
+                        end_path = true;
+                    } else {
+                        bounce++;
+                        if (bounce < P.bounce_limit) begin_trav = true;
+                        else { valid = 0; end_path = true; }                               // loop exhausted, :38 (Q7)
+                    }
+                }
+            }
+
+            // ---- S2: path end: pixel_color += dev_spectrum_to_XYZ(...) (rendering.cu:227, color.cu:88-104) --------
+            if (end_path) {
+                float wl[kWavelengths];
+                hero_expand(hero, wl);
+                const float delta_lambda = (kLambdaMax - kLambdaMin) / (float)kWavelengths;
+                float x = 0.0f, y = 0.0f, z = 0.0f;
+#pragma unroll
+                for (int k = 0; k < kWavelengths; k++) {
+                    if ((uint32_t)k < valid) {
+                        int off; float w;
+                        interp_coords(wl[k], off, w);
+                        const float4 r0 = s_cmf[off], r1 = s_cmf[off + 1];
+                        const float power = pw[k];
+                        x += ((1.0f - w) * r0.x + w * r1.x) * power * delta_lambda;
+                        y += ((1.0f - w) * r0.y + w * r1.y) * power * delta_lambda;
+                        z += ((1.0f - w) * r0.z + w * r1.z) * power * delta_lambda;
+                    }
+                }
+                acc = acc + mk(x, y, z);
+                have_path = false;
+            }
+
+            // ---- S3: pixel switch: all samples of the current pixel done (or no pixel yet) ------------------------
+            if (!dead && tv.node < 0 && !have_path && !begin_trav && (!have_pixel || sample == P.spp)) {
+                if (have_pixel && PROBE) {
+                    // cost of this pixel = node records it visited (+1 so that empty pixels still sort after real ones)
+                    atomicAdd(&P.tile_cost[cur_tile_local], ts.n_iters - pixel_iters0 + 1u);
+                    have_pixel = false;
+                }
+                if (have_pixel && !PROBE) {
+                    // store RNG state (rendering.cu:232) and save_to_fb (rendering.cu:140-149)
+                    P.rng[0 * (size_t)P.n_lanes + idx] = rs.d;
+                    P.rng[1 * (size_t)P.n_lanes + idx] = rs.v0;
+                    P.rng[2 * (size_t)P.n_lanes + idx] = rs.v1;
+                    P.rng[3 * (size_t)P.n_lanes + idx] = rs.v2;
+                    P.rng[4 * (size_t)P.n_lanes + idx] = rs.v3;
+                    P.rng[5 * (size_t)P.n_lanes + idx] = rs.v4;
+                    // pixel_color / float(spp) -> (1/spp) * v ; XYZ_to_sRGB (color.cu:35-41, vec3.cuh:80-91)
+                    const float inv_spp = 1.0f / (float)P.spp;
+                    const V3 c = inv_spp * acc;
+                    const float r_lin = (3.2404542f * c.x) + (-1.5371385f * c.y) + (-0.4985314f * c.z);
+                    const float g_lin = (-0.9692660f * c.x) + (1.8760108f * c.y) + (0.0415560f * c.z);
+                    const float b_lin = (0.0556434f * c.x) + (-0.2040259f * c.y) + (1.0572252f * c.z);
+                    const float r = correct_channel(r_lin), g = correct_channel(g_lin), b = correct_channel(b_lin);
+                    float *o = P.tile_out + out_slot;
+                    o[0 * kTileLanes] = (float)(int)(r * 255.99f);      // expand_sRGB (color.cu:43-49, Q15)
+                    o[1 * kTileLanes] = (float)(int)(g * 255.99f);
+                    o[2 * kTileLanes] = (float)(int)(b * 255.99f);
+                    o[3 * kTileLanes] = r; o[4 * kTileLanes] = g; o[5 * kTileLanes] = b;
+                    o[6 * kTileLanes] = acc.x; o[7 * kTileLanes] = acc.y; o[8 * kTileLanes] = acc.z;
+                    have_pixel = false;
+                }
+                // fetch the next pixel of this rank's queue (wave-aggregated atomic); skip slots outside the chunk
+                bool searching = true;
+                while (searching) {
+                    const unsigned long long m = __ballot(1);
+                    const int leader = __ffsll((long long)m) - 1;
+                    uint32_t base = 0;
+                    if ((int)lane == leader) base = atomicAdd(P.pixel_counter, (uint32_t)__popcll(m));
+                    base = (uint32_t)__shfl((int)base, leader, 64);
+                    const uint32_t pix = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                    if (pix >= n_local_pixels) { dead = true; searching = false; }
+                    else {
+                        const uint32_t tile_local = P.tile_order ? P.tile_order[pix >> 6] : (pix >> 6);   // cost-ordered queue
+                        const uint32_t lt = pix & 63u;
+                        const uint32_t tile = P.rank + P.world * tile_local;
+                        const uint32_t tile_x = tile % P.tiles_x, tile_y = tile / P.tiles_x;
+                        const uint32_t i = tile_x * 8u + (lt & 7u);          // chunk-relative column (rendering.cu:156)
+                        const uint32_t j = tile_y * 8u + (lt >> 3);          // chunk-relative row    (rendering.cu:157)
+                        // pixels outside the chunk (or the reference grid) never touch RNG or output (rendering.cu:205)
+                        if ((tile < P.n_tiles) && (i < P.width) && (j < P.height) && (i / P.tx < P.bx) && (j / P.ty < P.by)) {
+                            idx = block_linear_idx(i, j, P.tx, P.ty, P.bx);
+                            out_slot = tile_local * (uint32_t)(kTilePlanes * kTileLanes) + lt;
+                            // pixel_center = p00 + (float)i*du + (float)j*dv, i/j incl. the chunk offset (rendering.cu:76,221)
+                            pixel_center = (mk(P.p00[0], P.p00[1], P.p00[2]) + (float)(P.offx + i) * du) + (float)(P.offy + j) * dv;
+                            rs.d = P.rng[0 * (size_t)P.n_lanes + idx];      // rendering.cu:209
+                            rs.v0 = P.rng[1 * (size_t)P.n_lanes + idx];
+                            rs.v1 = P.rng[2 * (size_t)P.n_lanes + idx];
+                            rs.v2 = P.rng[3 * (size_t)P.n_lanes + idx];
+                            rs.v3 = P.rng[4 * (size_t)P.n_lanes + idx];
+                            rs.v4 = P.rng[5 * (size_t)P.n_lanes + idx];
+                            acc = mk(0.f, 0.f, 0.f);
+                            sample = 0;
+                            if (PROBE) { cur_tile_local = tile_local; pixel_iters0 = ts.n_iters; }
+                            have_pixel = true;
+                            searching = false;
+                        }
+                    }
+                }
+            }
+
+            // ---- S4: new camera ray: renderer::get_ray (rendering.cu:66-87) ----------------------------------------
+            if (!dead && tv.node < 0 && !have_path && !begin_trav && have_pixel && sample < P.spp) {
                 float px = -0.5f + rng_uniform(rs);                       // pixel_sample_square, :49-56
                 float py = -0.5f + rng_uniform(rs);
                 V3 pixel_sample = pixel_center + (px * du + py * dv);
@@ -120,166 +305,52 @@ __global__ __launch_bounds__(64) void render_kernel(const RenderParams P) {
                 }
                 ro = origin;
                 rd = pixel_sample - origin;                                // not normalised (Q10)
-                hero_wavelengths(rs, wl);                                  // ray ctor -> init_spectrum, ray.cuh:37-50
+                hero = hero_draw(rs);                                      // ray ctor -> init_spectrum, ray.cuh:37-50
 #pragma unroll
                 for (int k = 0; k < kWavelengths; k++) pw[k] = 1.0f;
                 valid = kWavelengths;
                 sample++;
                 bounce = 0;
-                need_path = false;
+                have_path = true;
+                if (P.bounce_limit > 0) begin_trav = true;
+                else { valid = 0; /* ray_bounce's loop body never runs (rendering.cu:22,38) */
+                       have_path = false; /* contributes dev_spectrum_to_XYZ(valid = 0) = 0 */ }
             }
-        }
-        if (__ballot(alive) == 0ull) break;
 
-        // ---- renderer::ray_bounce, one iteration of its loop (rendering.cu:22-36) ----------------------
-        bool end_path = false;
-        const bool trace = alive && (bounce < P.bounce_limit);
-        if (alive && !trace) { valid = 0; end_path = true; }               // loop exhausted, :38 (Q7)
-
-        float t_hit = 0.f;
-        int tri = bvh_closest_hit<COUNT>(P.nodes, P.tris, P.root_ref, ro, rd, my_stack, t_hit, trace, n_iters, n_tri, n_box);
-
-        if (trace) {
-            n_rays++;
-            if (tri < 0) {
-                // miss: r.mul_spectrum(background) and stop (rendering.cu:24-27)
-#pragma unroll
-                for (int k = 0; k < kWavelengths; k++) {
-                    if ((uint32_t)k < valid) {
-                        int off; float w;
-                        interp_coords(wl[k], off, w);
-                        pw[k] *= interp_pair(s_bg[off], w);
-                    }
-                }
-                end_path = true;
-            } else {
-                // rebuild the hit record from (t, triangle): tri::hit tail (tri.cu:36-39) + set_face_normal
-                const float4 ta = P.tris[3 * tri + 0];
-                const float4 tc = P.tris[3 * tri + 2];
-                const V3 n_geo = mk(ta.x, ta.y, ta.z);
-                const V3 hp = ro + t_hit * rd;                                          // ray::at, ray.cuh:31-34
-                const bool front_face = dot(rd, n_geo) < 0;                            // hit_record.cuh:41
-                const V3 n = front_face ? n_geo : -n_geo;
-                const uint32_t mat = __float_as_uint(tc.z) >> 8;
-                const float4 mp0 = P.mat_par[2 * mat + 0];
-                const float4 mp1 = P.mat_par[2 * mat + 1];
-                const uint32_t mtype = __float_as_uint(mp0.x);
-
-                // material::scatter (materials/material.cu:55-100)
-                V3 scatter_direction = mk(0.f, 0.f, 0.f);
-                float eps_sign = 1.0f;
-                bool did_scatter = true;
-                const V3 unit_in = unit_vector(rd);
-                if (mtype == 4u) {                                                      // EMISSIVE, :83-86
-                    did_scatter = false;
-                } else if (mtype == 2u) {                                               // DIELECTRIC, :73-80
-                    float ir = sellmeier_index(mp0.z, mp0.w, mp1.x, mp1.y, mp1.z, mp1.w, wl[0]);
-                    // refraction_scatter, :102-136
-                    float refraction_ratio = front_face ? (1.0f / ir) : ir;
-                    float cos_theta = fminf(dot(-unit_in, n), 1.0f);
-                    float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
-                    bool cannot_refract = refraction_ratio * sin_theta > 1.0f;
-                    if (!cannot_refract)                                                // short-circuit ||, :114
-                        cannot_refract = reflectance(cos_theta, refraction_ratio) > rng_uniform(rs);
-                    if (cannot_refract) {
-                        scatter_direction = reflect(unit_in, n);
-                    } else {
-                        scatter_direction = refract(unit_in, n, refraction_ratio);
-                        eps_sign = -1.0f;
-                        valid = 1;                                                      // :78-79 (Q6)
-                    }
-                } else {
-                    // METALLIC (:64-71) and LAMBERTIAN/default (:88-92) both start with random_unit_vector
-                    const V3 ruv = unit_vector(random_in_unit_sphere(rs));             // vec3.cuh:221-227
-                    if (mtype == 1u) {
-                        V3 reflected = reflect(unit_in, n);                            // reflection_scatter, :22-37
-                        scatter_direction = reflected + mp0.y * ruv;
-                        did_scatter = dot(scatter_direction, n) > 0;
-                        if (!did_scatter) valid = 0;
-                    } else {
-                        scatter_direction = n + ruv;                                   // lambertian_scatter, :8-19
-                        if (near_zero(scatter_direction)) scatter_direction = n;
-                    }
-                }
-                // r_in.mul_spectrum(spectral_distribution) (:95), after valid_wavelengths was updated (Q8)
-                const float2 *sd = P.mat_sd + (size_t)mat * 96u;
-#pragma unroll
-                for (int k = 0; k < kWavelengths; k++) {
-                    if ((uint32_t)k < valid) {
-                        int off; float w;
-                        interp_coords(wl[k], off, w);
-                        pw[k] *= interp_pair(sd[off], w);
-                    }
-                }
-                ro = hp + (eps_sign * kEpsilon) * n;                                    // :96 (Q9)
-                rd = scatter_direction;                                                 // :97
-                if (!did_scatter) {
-                    end_path = true;
-                } else {
-                    bounce++;
-                }
+            // ---- S5: start the closest-hit query: bvh::hit(r, 0, FLT_MAX, rec, root) (rendering.cu:24) --------------
+            if (begin_trav) {
+                n_rays++;
+                inv = mk(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);           // aabb.cu:17, hoisted out of the box test
+                if (trav_begin<ITERS>(tv, P.tris, P.root_ref, ro, rd, ts)) result_ready = true;
             }
         }
 
-        // ---- path end: pixel_color += dev_spectrum_to_XYZ(...) (rendering.cu:227, color.cu:88-104) ------
-        if (alive && end_path) {
-            const float delta_lambda = (kLambdaMax - kLambdaMin) / (float)kWavelengths;
-            float x = 0.0f, y = 0.0f, z = 0.0f;
-#pragma unroll
-            for (int k = 0; k < kWavelengths; k++) {
-                if ((uint32_t)k < valid) {
-                    int off; float w;
-                    interp_coords(wl[k], off, w);
-                    const float4 r0 = s_cmf[off], r1 = s_cmf[off + 1];
-                    const float power = pw[k];
-                    x += ((1.0f - w) * r0.x + w * r1.x) * power * delta_lambda;
-                    y += ((1.0f - w) * r0.y + w * r1.y) * power * delta_lambda;
-                    z += ((1.0f - w) * r0.z + w * r1.z) * power * delta_lambda;
-                }
+        // =========================== traversal phase =========================================================
+        const unsigned long long alive_mask = __ballot(!dead);
+        if (alive_mask == 0ull) break;
+        for (;;) {
+            const unsigned long long trav_mask = __ballot(tv.node >= 0);
+            if (trav_mask == 0ull) break;
+            if (__popcll(alive_mask & ~trav_mask) >= (int)P.shade_threshold) break;
+            if (COUNT) { ts.w_iters++; ts.w_alive += (uint32_t)__popcll(alive_mask); }
+            if (tv.node >= 0) {
+                trav_step<ITERS>(tv, P.nodes, P.tris, ro, rd, inv, my_stack, ts);
+                if (tv.node < 0) result_ready = true;
             }
-            acc = acc + mk(x, y, z);
-            need_path = true;
         }
     }
 
-    // ---- epilogue: store RNG state (rendering.cu:232) and save_to_fb (rendering.cu:140-149) --------------
-    if (in_image) {
-        P.rng[0 * (size_t)P.n_lanes + idx] = rs.d;
-        P.rng[1 * (size_t)P.n_lanes + idx] = rs.v0;
-        P.rng[2 * (size_t)P.n_lanes + idx] = rs.v1;
-        P.rng[3 * (size_t)P.n_lanes + idx] = rs.v2;
-        P.rng[4 * (size_t)P.n_lanes + idx] = rs.v3;
-        P.rng[5 * (size_t)P.n_lanes + idx] = rs.v4;
-    }
-    {
-        // pixel_color / float(spp) -> (1/spp) * v ; XYZ_to_sRGB (color.cu:35-41, vec3.cuh:80-91)
-        const float inv_spp = 1.0f / (float)P.spp;
-        const V3 c = inv_spp * acc;
-        const float r_lin = (3.2404542f * c.x) + (-1.5371385f * c.y) + (-0.4985314f * c.z);
-        const float g_lin = (-0.9692660f * c.x) + (1.8760108f * c.y) + (0.0415560f * c.z);
-        const float b_lin = (0.0556434f * c.x) + (-0.2040259f * c.y) + (1.0572252f * c.z);
-        const float r = correct_channel(r_lin), g = correct_channel(g_lin), b = correct_channel(b_lin);
-        float *o = P.tile_out + (size_t)blockIdx.x * (kTilePlanes * kTileLanes) + lane;
-        // expand_sRGB (color.cu:43-49): float(int(v*255.99f))  (Q15)
-        o[0 * kTileLanes] = in_image ? (float)(int)(r * 255.99f) : 0.f;
-        o[1 * kTileLanes] = in_image ? (float)(int)(g * 255.99f) : 0.f;
-        o[2 * kTileLanes] = in_image ? (float)(int)(b * 255.99f) : 0.f;
-        o[3 * kTileLanes] = in_image ? r : 0.f;
-        o[4 * kTileLanes] = in_image ? g : 0.f;
-        o[5 * kTileLanes] = in_image ? b : 0.f;
-        o[6 * kTileLanes] = acc.x;
-        o[7 * kTileLanes] = acc.y;
-        o[8 * kTileLanes] = acc.z;
-    }
     {
         uint32_t r = wave_sum(n_rays);
-        if (lane == 0 && r) atomicAdd(&P.counters[0], (unsigned long long)r);
+        if (!PROBE && lane == 0 && r) atomicAdd(&P.counters[0], (unsigned long long)r);
         if (COUNT) {
-            uint32_t a = wave_sum(n_iters), b = wave_sum(n_tri), c = wave_sum(n_box);
+            uint32_t a = wave_sum(ts.n_iters), b = wave_sum(ts.n_tri), c = wave_sum(ts.n_box);
             if (lane == 0) {
                 atomicAdd(&P.counters[1], (unsigned long long)a);
                 atomicAdd(&P.counters[2], (unsigned long long)b);
                 atomicAdd(&P.counters[3], (unsigned long long)c);
+                atomicAdd(&P.counters[4], (unsigned long long)ts.w_iters);   // wave-uniform
+                atomicAdd(&P.counters[5], (unsigned long long)ts.w_alive);
             }
         }
     }
@@ -329,9 +400,15 @@ __global__ __launch_bounds__(64) void trace_rays_kernel(const RenderParams P, co
     const bool active = k < n;
     V3 o = mk(0, 0, 0), d = mk(0, 0, 1);
     if (active) { o = mk(rays[6 * k + 0], rays[6 * k + 1], rays[6 * k + 2]); d = mk(rays[6 * k + 3], rays[6 * k + 4], rays[6 * k + 5]); }
-    uint32_t a = 0, b = 0, c = 0;
-    float t = 0.f;
-    int tri = bvh_closest_hit<false>(P.nodes, P.tris, P.root_ref, o, d, s_stack + lane, t, active, a, b, c);
+    TravStats ts;
+    Trav tv; tv.node = -1; tv.sp = 0; tv.c = kFltMax; tv.hit = -1;
+    const V3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    if (active) trav_begin<false>(tv, P.tris, P.root_ref, o, d, ts);
+    while (__ballot(tv.node >= 0) != 0ull) {
+        if (tv.node >= 0) trav_step<false>(tv, P.nodes, P.tris, o, d, inv, s_stack + lane, ts);
+    }
+    const float t = tv.c;
+    const int tri = tv.hit;
     if (active) {
         float ff = 0.f, mat = 0.f;
         if (tri >= 0) {
@@ -382,12 +459,26 @@ hipError_t launch_init_rng(uint32_t *rng, uint32_t n_lanes, uint64_t seed, hipSt
     return hipGetLastError();
 }
 
-hipError_t launch_render(const RenderParams &p, uint32_t tiles_local, bool count_traversal, hipStream_t st) {
-    if (tiles_local == 0) return hipSuccess;
+template <int MODE>
+static hipError_t launch_render_mode(const RenderParams &p, uint32_t n_cu, hipStream_t st) {
     const size_t lds = render_lds_bytes(p.stack_depth);
-    if (count_traversal) hipLaunchKernelGGL(render_kernel<true>, dim3(tiles_local), dim3(64), lds, st, p);
-    else hipLaunchKernelGGL(render_kernel<false>, dim3(tiles_local), dim3(64), lds, st, p);
+    // persistent waves: as many 1-wave workgroups as the chip holds at this kernel's occupancy, never more than tiles
+    int per_cu = 0;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_kernel<MODE>, 64, lds);
+    if (e != hipSuccess || per_cu <= 0) { (void)hipGetLastError(); per_cu = 16; }
+    if (per_cu > 32) per_cu = 32;
+    if (p.waves_per_cu_override > 0) per_cu = (int)p.waves_per_cu_override;
+    uint32_t n_waves = n_cu * (uint32_t)per_cu;
+    if (n_waves > p.tiles_local) n_waves = p.tiles_local;
+    hipLaunchKernelGGL(render_kernel<MODE>, dim3(n_waves), dim3(64), lds, st, p);
     return hipGetLastError();
+}
+
+hipError_t launch_render(const RenderParams &p, uint32_t n_cu, int mode, hipStream_t st) {
+    if (p.tiles_local == 0) return hipSuccess;
+    if (mode == 1) return launch_render_mode<1>(p, n_cu, st);
+    if (mode == 2) return launch_render_mode<2>(p, n_cu, st);
+    return launch_render_mode<0>(p, n_cu, st);
 }
 
 hipError_t launch_scatter(const ScatterParams &p, hipStream_t st) {

@@ -96,7 +96,9 @@ class Renderer:
     def stats(self):
         st = B.Stats()
         self._ck(B.lib().srt_get_stats(self._h, C.byref(st)))
-        return {k: getattr(st, k) for k in ("rays", "paths", "node_visits", "tri_tests", "box_tests")}
+        d = {k: getattr(st, k) for k in ("rays", "paths", "node_visits", "tri_tests", "box_tests")}
+        d["util"] = list(st.util)
+        return d
 
     def last_kernel_ms(self):
         ms = C.c_float()

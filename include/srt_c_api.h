@@ -79,7 +79,11 @@ typedef struct {
     uint64_t node_visits;   /* traversal iterations = paired-child records fetched (V) */
     uint64_t tri_tests;     /* leaf (triangle) tests (T) */
     uint64_t box_tests;
-    uint64_t reserved[3];
+    /* instrumented kernel only, wave-level utilisation: [0] traversal-loop trips, [1] box-segment executions,
+     * [2] lanes active in them, [3] triangle-segment executions, [4] lanes active in them, [5] outer (per-ray)
+     * loop trips, [6] lanes tracing in them.  SIMD utilisation of traversal = node_visits / (64 * util[0]). */
+    uint64_t util[7];
+    uint64_t reserved[4];
 } srt_stats;
 
 typedef struct srt_scene srt_scene;   /* host-side flattened scene (replaces scene_manager's device heap) */

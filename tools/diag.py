@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""GPU diagnostic: instrumented render of a scene, prints per-ray work and wave utilisation."""
+import argparse, importlib, json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+srt = importlib.import_module("cuda-spectral-ray-tracer_amd")
+ap = argparse.ArgumentParser()
+ap.add_argument("--scene", type=int, default=100); ap.add_argument("--bvh", type=int, default=1)
+ap.add_argument("--width", type=int, default=1920); ap.add_argument("--height", type=int, default=1080)
+ap.add_argument("--spp", type=int, default=16); ap.add_argument("--depth", type=int, default=16)
+ap.add_argument("--reps", type=int, default=2)
+a = ap.parse_args()
+scene = srt.Scene.builtin(a.scene, 0).build_bvh(a.bvh, 1984)
+cam = scene.default_camera(a.width, a.height)
+r = srt.Renderer(0)
+r.upload_scene(scene); r.set_camera(cam); r.set_partition(0, 1)
+res = {"tris": scene.n_tris, "nodes": scene.n_nodes, "depth": scene.bvh_depth}
+for count in (True, False):
+    r.set_count_traversal(count)
+    best = 1e30
+    for _ in range(a.reps):
+        r.init_device_params(a.width, a.height, a.spp, a.depth, 1984)
+        r.render_chunk(a.width, a.height)
+        r.synchronize()
+        best = min(best, r.last_kernel_ms())
+    st = r.stats()
+    if count:
+        u = st["util"]
+        res.update(rays=st["rays"], rays_per_path=st["rays"] / st["paths"], V=st["node_visits"] / st["rays"], T=st["tri_tests"] / st["rays"],
+                   Bx=st["box_tests"] / st["rays"],
+                   trav_simd_util=st["node_visits"] / (64.0 * u[0]), alive_frac=u[1] / (64.0 * u[0]), trav_over_alive=st["node_visits"] / max(u[1], 1), ms_instrumented=best)
+    else:
+        res.update(ms=best, mray_s=st["rays"] / best / 1e3)
+print(json.dumps(res, indent=1))
