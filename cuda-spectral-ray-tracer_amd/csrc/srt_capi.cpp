@@ -37,7 +37,7 @@ struct srt_ctx {
     size_t tiles_capacity = 0;      // floats
     unsigned long long *d_counters = nullptr;     // [kCounters] statistics + 1 word pixel-queue head behind them
     int n_cu = 256;
-    uint32_t shade_threshold = 4, waves_per_cu = 0;    // tuning knobs (env SRT_SHADE_THRESHOLD / SRT_WAVES_PER_CU)
+    uint32_t shade_threshold = 20, waves_per_cu = 0;   // tuning knobs (env SRT_SHADE_THRESHOLD / SRT_WAVES_PER_CU)
     uint32_t probe_spp = 2;                            // samples of the cost probe (env SRT_PROBE_SPP, 0 = no ordering)
     uint32_t *d_tile_cost = nullptr, *d_tile_order = nullptr;
     size_t tile_sched_capacity = 0;

@@ -221,6 +221,7 @@ __device__ __forceinline__ bool box_test(float lox, float hix, float loy, float 
 // stack[k*64]), so a wave can interleave traversal steps of some lanes with shading of others.
 struct TravStats {
     uint32_t n_iters = 0, n_tri = 0, n_box = 0;   // per lane: node records visited, triangle / box tests
+    uint32_t n_nan = 0;                            // per lane: queries answered without traversal (NaN direction)
     uint32_t w_iters = 0;                          // wave: traversal steps executed (every lane counts the same)
     uint32_t w_alive = 0;                          // wave: sum over those steps of lanes that still own work
 };
@@ -236,6 +237,16 @@ struct Trav {
 template <bool COUNT>
 __device__ __forceinline__ bool trav_begin(Trav &tv, const float4 *__restrict__ tris, int root_ref, V3 o, V3 d, TravStats &ts) {
     tv.c = kFltMax; tv.hit = -1; tv.sp = 0;
+    // A direction with a NaN component can never hit anything: every product with it is NaN (0*NaN included), so
+    // dot(n, dir) is NaN, `fabs(denom) < 1e-8` is false, t = x/NaN is NaN and `0 <= t` is false for EVERY triangle
+    // (tri.cu:12-23), while every box test passes (all comparisons false, aabb.cu:30-36).  The reference therefore
+    // walks the whole tree and returns "miss" (NaN IOR from the Sellmeier quirk Q1); the result is known
+    // without walking.  The instrumented build records the skipped query in ts.n_nan.
+    if (d.x != d.x || d.y != d.y || d.z != d.z) {
+        if (COUNT) ts.n_nan++;
+        tv.node = -1;
+        return true;
+    }
     if (root_ref < 0) {   // root is a leaf: only one element
         float t;
         if (COUNT) ts.n_tri++;

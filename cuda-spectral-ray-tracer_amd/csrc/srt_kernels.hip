@@ -352,6 +352,10 @@ __global__ __launch_bounds__(64) void render_kernel(const RenderParams P) {
                 atomicAdd(&P.counters[4], (unsigned long long)ts.w_iters);   // wave-uniform
                 atomicAdd(&P.counters[5], (unsigned long long)ts.w_alive);
             }
+            const uint32_t nn = wave_sum(ts.n_nan);
+            if (lane == 0) {
+                atomicAdd(&P.counters[6], (unsigned long long)nn);
+            }
         }
     }
 }

@@ -79,9 +79,10 @@ typedef struct {
     uint64_t node_visits;   /* traversal iterations = paired-child records fetched (V) */
     uint64_t tri_tests;     /* leaf (triangle) tests (T) */
     uint64_t box_tests;
-    /* instrumented kernel only, wave-level utilisation: [0] traversal-loop trips, [1] box-segment executions,
-     * [2] lanes active in them, [3] triangle-segment executions, [4] lanes active in them, [5] outer (per-ray)
-     * loop trips, [6] lanes tracing in them.  SIMD utilisation of traversal = node_visits / (64 * util[0]). */
+    /* instrumented kernel only: [0] wave-level traversal steps, [1] sum over those steps of lanes that still own
+     * work, [2] closest-hit queries answered without traversal because the direction is NaN (the reference walks
+     * the whole tree for them and finds nothing).  SIMD utilisation of traversal =
+     * node_visits / (64 * util[0]).  node_visits / tri_tests / box_tests count the work actually done. */
     uint64_t util[7];
     uint64_t reserved[4];
 } srt_stats;
