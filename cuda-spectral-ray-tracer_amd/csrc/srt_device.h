@@ -258,7 +258,21 @@ __device__ __forceinline__ bool trav_begin(Trav &tv, const float4 *__restrict__ 
     return false;
 }
 
+// Two fp32 values per lane; + and * on it compile to v_pk_add_f32 / v_pk_mul_f32, which round each half exactly like the
+// scalar instructions (checked on the device by the op sweep, ops 14-16).
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 mk2(float a, float b) { f2 r; r.x = a; r.y = b; return r; }
+
 // One iteration of the do-while of bvh.cu:120-162 for a lane with tv.node >= 0.
+//
+// The reference handles the two children one after the other (leaf -> tri::hit, internal -> aabb::hit), which on a
+// wave means four divergent code segments per visit.  Everything except the comparisons against closest_so_far is
+// independent of it, so this version computes the c-independent parts of BOTH children together -- both slab tests
+// with packed fp32, both triangle tests in one merged segment -- and then applies the c-dependent decisions in the
+// reference's order (left, then right with the updated closest):
+//   box  : pass  <=>  !(min(c, t1x, t1y, t1z) <= max(tmin, t0x, t0y, t0z))     (aabb.cu:30-36)
+//   tri  : hit   <=>  !(|denom| < 1e-8) && tmin <= t && t <= c && inside        (tri.cu:12-28)
+// Same expressions, same operand order per value; only the instruction schedule differs.
 template <bool COUNT>
 __device__ __forceinline__ void trav_step(Trav &tv, const float4 *__restrict__ nodes, const float4 *__restrict__ tris, V3 o, V3 d,
                                           V3 inv, uint32_t *stack, TravStats &ts) {
@@ -268,24 +282,56 @@ __device__ __forceinline__ void trav_step(Trav &tv, const float4 *__restrict__ n
     const float4 q2 = nodes[4 * node + 2];
     const float4 q3 = nodes[4 * node + 3];
     const int lref = (int)__float_as_uint(q3.x), rref = (int)__float_as_uint(q3.y);
-    if (COUNT) ts.n_iters++;
-    bool trav_l = false, trav_r = false;
-    if (lref < 0) {
-        float t;
-        if (COUNT) ts.n_tri++;
-        if (tri_test(tris, ~lref, o, d, 0.0f, tv.c, t)) { tv.c = t; tv.hit = ~lref; }
-    } else {
-        if (COUNT) ts.n_box++;
-        trav_l = box_test(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, inv, 0.0f, tv.c);
+    const bool leaf_l = lref < 0, leaf_r = rref < 0;
+    if (COUNT) { ts.n_iters++; ts.n_tri += (leaf_l ? 1u : 0u) + (leaf_r ? 1u : 0u); ts.n_box += (leaf_l ? 0u : 1u) + (leaf_r ? 0u : 1u); }
+
+    // ---- both child boxes (x = left, y = right); a leaf child's slot holds a box too, its result is ignored -------
+    const bool px = inv.x >= 0, py = inv.y >= 0, pz = inv.z >= 0;
+    const f2 lox = mk2(q0.x, q1.z), hix = mk2(q0.y, q1.w), loy = mk2(q0.z, q2.x), hiy = mk2(q0.w, q2.y), loz = mk2(q1.x, q2.z), hiz = mk2(q1.y, q2.w);
+    const f2 t0x = ((px ? lox : hix) - o.x) * inv.x, t1x = ((px ? hix : lox) - o.x) * inv.x;
+    const f2 t0y = ((py ? loy : hiy) - o.y) * inv.y, t1y = ((py ? hiy : loy) - o.y) * inv.y;
+    const f2 t0z = ((pz ? loz : hiz) - o.z) * inv.z, t1z = ((pz ? hiz : loz) - o.z) * inv.z;
+    const float e_l = fmaxf(fmaxf(fmaxf(0.0f, t0x.x), t0y.x), t0z.x), e_r = fmaxf(fmaxf(fmaxf(0.0f, t0x.y), t0y.y), t0z.y);
+    // min(c, t1x, t1y, t1z) = min(c, m) with m = min over the non-NaN t1 (fminf ignores NaNs in any order)
+    const float m_l = fminf(fminf(t1x.x, t1y.x), t1z.x), m_r = fminf(fminf(t1x.y, t1y.y), t1z.y);
+
+    // ---- both leaf triangles in one segment ------------------------------------------------------------------------
+    float t_l = 0.f, t_r = 0.f;
+    bool ok_l = false, ok_r = false;          // plane not parallel, t >= tmin, inside (everything but `t <= c`)
+    if (leaf_l || leaf_r) {
+        const int il = leaf_l ? ~lref : 0, ir = leaf_r ? ~rref : 0;
+        const float4 al = tris[3 * il + 0], ar = tris[3 * ir + 0];
+        const float4 bl = tris[3 * il + 1], br = tris[3 * ir + 1];
+        const float4 cl = tris[3 * il + 2], cr = tris[3 * ir + 2];
+        const f2 nx = mk2(al.x, ar.x), ny = mk2(al.y, ar.y), nz = mk2(al.z, ar.z), D = mk2(al.w, ar.w);
+        const f2 denom = nx * d.x + ny * d.y + nz * d.z;                      // dot(normal, dir), tri.cu:9
+        const f2 num = D - (nx * o.x + ny * o.y + nz * o.z);                  // D - dot(normal, origin), tri.cu:17
+        const f2 t = mk2(num.x / denom.x, num.y / denom.y);
+        const uint32_t fl = __float_as_uint(cl.z), fr = __float_as_uint(cr.z);
+        const bool wyl = fl & kTriWIsY, hzl = fl & kTriHIsZ, wyr = fr & kTriWIsY, hzr = fr & kTriHIsZ;
+        // intersection = orig + t*dir (ray.cuh:31-34), the two projected components
+        const f2 pw = mk2(wyl ? o.y : o.x, wyr ? o.y : o.x) + t * mk2(wyl ? d.y : d.x, wyr ? d.y : d.x);
+        const f2 ph = mk2(hzl ? o.z : o.y, hzr ? o.z : o.y) + t * mk2(hzl ? d.z : d.y, hzr ? d.z : d.y);
+        // double_signed_area_2D(v1,v2,v3) = (v1[w]-v3[w])*(v2[h]-v3[h]) - (v2[w]-v3[w])*(v1[h]-v3[h])   (tri.cu:181)
+        const f2 v0w = mk2(bl.x, br.x), v0h = mk2(bl.y, br.y), v1w = mk2(bl.z, br.z), v1h = mk2(bl.w, br.w), v2w = mk2(cl.x, cr.x), v2h = mk2(cl.y, cr.y);
+        const f2 a1 = (pw - v1w) * (v0h - v1h) - (v0w - v1w) * (ph - v1h);     // (p, v0, v1)
+        const f2 a2 = (pw - v2w) * (v1h - v2h) - (v1w - v2w) * (ph - v2h);     // (p, v1, v2)
+        const f2 a3 = (pw - v0w) * (v2h - v0h) - (v2w - v0w) * (ph - v0h);     // (p, v2, v0)
+        const bool in_l = (fl & kTriClockwise) ? (a1.x >= 0.f && a2.x >= 0.f && a3.x >= 0.f) : (a1.x <= 0.f && a2.x <= 0.f && a3.x <= 0.f);
+        const bool in_r = (fr & kTriClockwise) ? (a1.y >= 0.f && a2.y >= 0.f && a3.y >= 0.f) : (a1.y <= 0.f && a2.y <= 0.f && a3.y <= 0.f);
+        t_l = t.x; t_r = t.y;
+        ok_l = leaf_l && !(fabsf(denom.x) < 1e-8f) && (0.0f <= t.x) && in_l;
+        ok_r = leaf_r && !(fabsf(denom.y) < 1e-8f) && (0.0f <= t.y) && in_r;
     }
-    if (rref < 0) {
-        float t;
-        if (COUNT) ts.n_tri++;
-        if (tri_test(tris, ~rref, o, d, 0.0f, tv.c, t)) { tv.c = t; tv.hit = ~rref; }
-    } else {
-        if (COUNT) ts.n_box++;
-        trav_r = box_test(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, inv, 0.0f, tv.c);
-    }
+
+    // ---- decisions in the reference's order (bvh.cu:128-160) -------------------------------------------------------
+    float c = tv.c;
+    bool trav_l, trav_r;
+    if (leaf_l) { trav_l = false; if (ok_l && t_l <= c) { c = t_l; tv.hit = ~lref; } }
+    else trav_l = !(fminf(c, m_l) <= e_l);
+    if (leaf_r) { trav_r = false; if (ok_r && t_r <= c) { c = t_r; tv.hit = ~rref; } }
+    else trav_r = !(fminf(c, m_r) <= e_r);
+    tv.c = c;
     if (!trav_l && !trav_r) {
         if (tv.sp == 0) tv.node = -1;
         else { tv.sp--; tv.node = (int)stack[tv.sp * 64]; }

@@ -449,6 +449,9 @@ __global__ void op_sweep_kernel(int which, const float *a, const float *b, uint3
     case 11: r = x * y + y; break;                      // must NOT contract into an fma
     case 12: r = (float)__float_as_uint(x); break;      // u32 -> f32 conversion (RNG uniform mapping)
     case 13: r = x * x + y * y + x * y; break;          // dot-style chain, left associated
+    case 14: { f2 a2 = mk2(x, y), b2 = mk2(y, x); f2 c2 = a2 * b2; r = c2.x; if (k & 1) r = c2.y; } break;          // v_pk_mul_f32
+    case 15: { f2 a2 = mk2(x, y), b2 = mk2(y, x * 0.5f); f2 c2 = a2 + b2; r = (k & 1) ? c2.y : c2.x; } break;    // v_pk_add_f32
+    case 16: { f2 a2 = mk2(x, y), b2 = mk2(y, x); f2 c2 = (a2 - b2) * x - a2 * b2; r = (k & 1) ? c2.y : c2.x; } break;
     default: r = 0.f;
     }
     out[k] = r;

@@ -40,6 +40,12 @@ def test_primitive_op_sweep(gpu, orc):
             assert np.all(ok), which
         else:
             assert _same(got, want), "op %d differs on %d operands" % (which, int(np.sum(bits(got) != bits(want))))
+    # packed fp32 (v_pk_mul_f32 / v_pk_add_f32) rounds each half like the scalar instruction
+    with np.errstate(all="ignore"):
+        odd = (np.arange(n) & 1).astype(bool)
+        assert _same(gpu.op_sweep(14, a, b), a * b)
+        assert _same(gpu.op_sweep(15, a, b), np.where(odd, b + a * np.float32(0.5), a + b))
+        assert _same(gpu.op_sweep(16, a, b), np.where(odd, ((b - a) * a) - (b * a), ((a - b) * a) - (a * b)))
     # u32 -> f32 (RNG mapping) and the truncating cast used by spectrum_interp / expand_sRGB
     got = gpu.op_sweep(12, a, b)
     assert _same(got, a.view(np.uint32).astype(np.float32))
