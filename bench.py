@@ -71,7 +71,7 @@ def main():
     ap.add_argument("--bvh", type=int, default=1)              # SRT_BVH_SAH for the synthetic scenes
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pmc-traffic-bytes", type=float, default=None,
-                    help="HBM bytes per launch from a separate rocprofv3 --pmc pass (profiles/), echoed as roofline.traffic")
+                    help="HBM bytes per launch from a separate rocprofv3 --pmc pass; default: profiles/r01/hbm_traffic.json when the workload matches")
     args = ap.parse_args()
 
     import torch
@@ -177,6 +177,12 @@ def main():
 
     if rank == 0:
         steps = max(args.steps, 1)
+        traffic = args.pmc_traffic_bytes
+        if traffic is None and world == 1 and (args.scene, W, H, args.spp, args.depth, args.bvh) == (100, 1920, 1080, 1024, 16, 1):
+            try:      # measured once with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on this exact workload
+                traffic = json.load(open(os.path.join(ROOT, "profiles", "r01", "hbm_traffic.json")))["hbm_bytes_per_launch"]
+            except Exception:
+                traffic = None
         mray = total_rays / elapsed / 1e6
         rays_per_launch_rank0 = rays_local / steps
         achieved = rays_per_launch_rank0 * b_ray / (kms * 1e-3) / 1e9            # GB/s, dominant kernel on this rank
@@ -191,9 +197,10 @@ def main():
             "rays_per_path": rays_per_path, "node_records_per_ray_V": V, "tri_tests_per_ray_T": T, "algorithmic_bytes_per_ray": b_ray,
             "kernel_ms_per_step": kms,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": args.pmc_traffic_bytes,
-                         "note": "algorithmic bytes (V*64 + T*48 + 56 per ray) / render-kernel time; the scene is L2-resident, "
-                                 "so real HBM traffic is far below this figure (see profiles/)"},
+                         "traffic": traffic,
+                         "note": "achieved = algorithmic bytes (V*64 + T*48 + 56 per ray) / render-kernel time. The scene is "
+                                 "LDS/L2-resident, so these bytes never reach HBM (traffic = measured HBM bytes per launch, "
+                                 "profiles/r01/hbm_traffic.json): the kernel is VALU / L1-gather bound, a frac above 1 is possible"},
         }
         if not args.no_cpu_baseline:
             try:

@@ -18,7 +18,8 @@ struct srt_ctx {
     std::string err;
     // scene images in HBM
     float *d_nodes = nullptr, *d_tris = nullptr, *d_mat_sd = nullptr, *d_mat_par = nullptr, *d_bg = nullptr, *d_cmf = nullptr;
-    int root_ref = 0, stack_depth = 1;
+    int root_ref = 0, stack_depth = 1, n_inner = 0, n_records = 0;
+    uint32_t n_tris = 0;
     uint32_t n_materials = 0;
     bool scene_ready = false, camera_ready = false, params_ready = false;
     srt_camera_data cam;
@@ -37,7 +38,8 @@ struct srt_ctx {
     size_t tiles_capacity = 0;      // floats
     unsigned long long *d_counters = nullptr;     // [kCounters] statistics + 1 word pixel-queue head behind them
     int n_cu = 256;
-    uint32_t shade_threshold = 20, waves_per_cu = 0;   // tuning knobs (env SRT_SHADE_THRESHOLD / SRT_WAVES_PER_CU)
+    uint32_t fringe_threshold = 20;                    // env SRT_FRINGE_THRESHOLD
+    uint32_t shade_threshold = 32, waves_per_cu = 0;   // tuning knobs (env SRT_SHADE_THRESHOLD / SRT_WAVES_PER_CU)
     uint32_t probe_spp = 2;                            // samples of the cost probe (env SRT_PROBE_SPP, 0 = no ordering)
     uint32_t *d_tile_cost = nullptr, *d_tile_order = nullptr;
     size_t tile_sched_capacity = 0;
@@ -78,6 +80,8 @@ void fill_params(const srt_ctx *c, RenderParams &p) {
     p.mat_sd = (const float2 *)c->d_mat_sd; p.mat_par = (const float4 *)c->d_mat_par;
     p.bg_sd = (const float2 *)c->d_bg; p.cmf = (const float4 *)c->d_cmf;
     p.root_ref = c->root_ref; p.stack_depth = c->stack_depth; p.n_materials = c->n_materials;
+    p.n_inner = c->n_inner; p.n_cached = 0;   // n_cached is set by the launcher
+    p.n_tris = c->n_tris; p.n_records = c->n_records;
     for (int k = 0; k < 3; k++) {
         p.du[k] = c->cam.pixel_delta_u[k]; p.dv[k] = c->cam.pixel_delta_v[k]; p.p00[k] = c->cam.pixel00_loc[k];
         p.center[k] = c->cam.camera_center[k]; p.disk_u[k] = c->cam.defocus_disk_u[k]; p.disk_v[k] = c->cam.defocus_disk_v[k];
@@ -110,6 +114,7 @@ int srt_create(int device, srt_ctx **out) {
     if (const char *ev = getenv("SRT_SHADE_THRESHOLD")) c->shade_threshold = (uint32_t)std::max(1, atoi(ev));
     if (const char *ev = getenv("SRT_WAVES_PER_CU")) c->waves_per_cu = (uint32_t)std::max(0, atoi(ev));
     if (const char *ev = getenv("SRT_PROBE_SPP")) c->probe_spp = (uint32_t)std::max(0, atoi(ev));
+    if (const char *ev = getenv("SRT_FRINGE_THRESHOLD")) c->fringe_threshold = (uint32_t)std::max(1, atoi(ev));
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->n_cu = prop.multiProcessorCount;
@@ -148,13 +153,14 @@ int srt_upload_scene(srt_ctx *c, const srt_scene *s) {
     FlatScene f;
     int rc = flatten_scene(*s, f);
     if (rc != SRT_OK) return fail(c, rc, global_error());
-    if (render_lds_bytes(f.stack_depth) > 64 * 1024) return fail(c, SRT_ERR_BVH, "srt_upload_scene: BVH too deep for the LDS traversal stack");
+    if (render_lds_bytes(f.stack_depth, 1, 0) > 64 * 1024) return fail(c, SRT_ERR_BVH, "srt_upload_scene: BVH too deep for the LDS traversal stack");
     if ((rc = upload(c, &c->d_nodes, f.nodes)) != SRT_OK) return rc;
     if ((rc = upload(c, &c->d_tris, f.tris)) != SRT_OK) return rc;
     if ((rc = upload(c, &c->d_mat_sd, f.mat_sd)) != SRT_OK) return rc;
     if ((rc = upload(c, &c->d_mat_par, f.mat_par)) != SRT_OK) return rc;
     if ((rc = upload(c, &c->d_bg, f.bg_sd)) != SRT_OK) return rc;
     c->root_ref = f.root_ref; c->stack_depth = f.stack_depth; c->n_materials = (uint32_t)s->mats.size();
+    c->n_inner = f.n_inner; c->n_records = f.n_records; c->n_tris = (uint32_t)s->raw.size();
     c->scene_ready = true;
     return SRT_OK;
 }
@@ -224,6 +230,7 @@ int srt_render_chunk(srt_ctx *c, uint32_t width, uint32_t height, uint32_t offx,
     p.tiles_local = c->tiles_local;
     p.pixel_counter = (uint32_t *)(c->d_counters + kCounters);
     p.shade_threshold = c->shade_threshold;
+    p.fringe_threshold = c->fringe_threshold;
     p.waves_per_cu_override = c->waves_per_cu;
     // ---- cost-ordered pixel queue --------------------------------------------------------------------------------
     // A pixel is one sequential RNG stream, so the launch cannot finish before its most expensive pixel does.  A short

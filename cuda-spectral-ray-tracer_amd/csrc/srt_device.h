@@ -224,6 +224,7 @@ struct TravStats {
     uint32_t n_nan = 0;                            // per lane: queries answered without traversal (NaN direction)
     uint32_t w_iters = 0;                          // wave: traversal steps executed (every lane counts the same)
     uint32_t w_alive = 0;                          // wave: sum over those steps of lanes that still own work
+    uint32_t w_fringe = 0, l_fringe = 0, l_inner = 0;   // wave: fringe steps, lanes served by fringe / inner steps
 };
 
 struct Trav {
@@ -273,36 +274,102 @@ __device__ __forceinline__ f2 mk2(float a, float b) { f2 r; r.x = a; r.y = b; re
 //   box  : pass  <=>  !(min(c, t1x, t1y, t1z) <= max(tmin, t0x, t0y, t0z))     (aabb.cu:30-36)
 //   tri  : hit   <=>  !(|denom| < 1e-8) && tmin <= t && t <= c && inside        (tri.cu:12-28)
 // Same expressions, same operand order per value; only the instruction schedule differs.
-template <bool COUNT>
-__device__ __forceinline__ void trav_step(Trav &tv, const float4 *__restrict__ nodes, const float4 *__restrict__ tris, V3 o, V3 d,
-                                          V3 inv, uint32_t *stack, TravStats &ts) {
-    const int node = tv.node;
-    const float4 q0 = nodes[4 * node + 0];
-    const float4 q1 = nodes[4 * node + 1];
-    const float4 q2 = nodes[4 * node + 2];
-    const float4 q3 = nodes[4 * node + 3];
-    const int lref = (int)__float_as_uint(q3.x), rref = (int)__float_as_uint(q3.y);
-    const bool leaf_l = lref < 0, leaf_r = rref < 0;
-    if (COUNT) { ts.n_iters++; ts.n_tri += (leaf_l ? 1u : 0u) + (leaf_r ? 1u : 0u); ts.n_box += (leaf_l ? 0u : 1u) + (leaf_r ? 0u : 1u); }
+// Paired-child record fetch: the first n_cached records (top of the tree, breadth-first) live in LDS.  The LDS pointer
+// keeps its address space so that the two sides stay ds_read_b128 / global_load_dwordx4 (a generic pointer would let
+// the compiler merge them into one flat_load through a selected address).
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const f4v lds_cf4;
+__device__ __forceinline__ f4v as_f4v(u4v v) { return __builtin_bit_cast(f4v, v); }
 
-    // ---- both child boxes (x = left, y = right); a leaf child's slot holds a box too, its result is ignored -------
+// Global scene arrays are read through buffer descriptors: buffer_load_dwordx4 with a 32-bit byte offset.  The
+// intrinsic keeps every load a full 16-byte access (plain loads get re-shaped into dwordx3 / dwordx2 pieces when a
+// component is unused) and the hardware range check turns an out-of-range index into zeros instead of a fault.
+typedef __amdgpu_buffer_rsrc_t buf_rsrc;
+__device__ __forceinline__ buf_rsrc make_rsrc(const void *base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ f4v buf_load16(buf_rsrc r, uint32_t byte_offset) {
+    return as_f4v(__builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_offset, 0, 0));
+}
+
+struct NodeSrc {
+    buf_rsrc global_nodes;
+    lds_cf4 *lds_nodes;
+    int n_cached;
+};
+__device__ __forceinline__ void fetch_node(const NodeSrc &ns, int node, f4v &q0, f4v &q1, f4v &q2, f4v &q3) {
+    if (node < ns.n_cached) {
+        lds_cf4 *p = ns.lds_nodes + 4 * node;
+        q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3];
+    } else {
+        const uint32_t off = (uint32_t)node * 64u;
+        q0 = buf_load16(ns.global_nodes, off); q1 = buf_load16(ns.global_nodes, off + 16u);
+        q2 = buf_load16(ns.global_nodes, off + 32u); q3 = buf_load16(ns.global_nodes, off + 48u);
+    }
+}
+
+// c-independent part of both slab tests (x = left child, y = right child), packed fp32.
+__device__ __forceinline__ void box_pair(const f4v &q0, const f4v &q1, const f4v &q2, V3 o, V3 inv, float &e_l, float &m_l,
+                                         float &e_r, float &m_r) {
     const bool px = inv.x >= 0, py = inv.y >= 0, pz = inv.z >= 0;
     const f2 lox = mk2(q0.x, q1.z), hix = mk2(q0.y, q1.w), loy = mk2(q0.z, q2.x), hiy = mk2(q0.w, q2.y), loz = mk2(q1.x, q2.z), hiz = mk2(q1.y, q2.w);
     const f2 t0x = ((px ? lox : hix) - o.x) * inv.x, t1x = ((px ? hix : lox) - o.x) * inv.x;
     const f2 t0y = ((py ? loy : hiy) - o.y) * inv.y, t1y = ((py ? hiy : loy) - o.y) * inv.y;
     const f2 t0z = ((pz ? loz : hiz) - o.z) * inv.z, t1z = ((pz ? hiz : loz) - o.z) * inv.z;
-    const float e_l = fmaxf(fmaxf(fmaxf(0.0f, t0x.x), t0y.x), t0z.x), e_r = fmaxf(fmaxf(fmaxf(0.0f, t0x.y), t0y.y), t0z.y);
+    e_l = fmaxf(fmaxf(fmaxf(0.0f, t0x.x), t0y.x), t0z.x); e_r = fmaxf(fmaxf(fmaxf(0.0f, t0x.y), t0y.y), t0z.y);
     // min(c, t1x, t1y, t1z) = min(c, m) with m = min over the non-NaN t1 (fminf ignores NaNs in any order)
-    const float m_l = fminf(fminf(t1x.x, t1y.x), t1z.x), m_r = fminf(fminf(t1x.y, t1y.y), t1z.y);
+    m_l = fminf(fminf(t1x.x, t1y.x), t1z.x); m_r = fminf(fminf(t1x.y, t1y.y), t1z.y);
+}
+
+__device__ __forceinline__ void trav_advance(Trav &tv, bool trav_l, bool trav_r, int lref, int rref, uint32_t *stack) {
+    if (!trav_l && !trav_r) {                       // bvh.cu:154-155: pop
+        if (tv.sp == 0) tv.node = -1;
+        else { tv.sp--; tv.node = (int)stack[tv.sp * 64]; }
+    } else {                                        // bvh.cu:156-160: descend left first, push right iff both
+        tv.node = trav_l ? lref : rref;
+        if (trav_l && trav_r) { stack[tv.sp * 64] = (uint32_t)rref; tv.sp++; }
+    }
+}
+
+// Visit of an INNER record (both children internal): two box tests, no triangle work.
+template <bool COUNT>
+__device__ __forceinline__ void trav_step_inner(Trav &tv, const NodeSrc &ns, V3 o, V3 inv, uint32_t *stack, TravStats &ts) {
+    f4v q0, q1, q2, q3;
+    fetch_node(ns, tv.node, q0, q1, q2, q3);
+    const int lref = (int)__float_as_uint(q3.x), rref = (int)__float_as_uint(q3.y);
+    if (COUNT) { ts.n_iters++; ts.n_box += 2u; }
+    float e_l, m_l, e_r, m_r;
+    box_pair(q0, q1, q2, o, inv, e_l, m_l, e_r, m_r);
+    const float c = tv.c;
+    const bool trav_l = !(fminf(c, m_l) <= e_l);
+    const bool trav_r = !(fminf(c, m_r) <= e_r);
+    trav_advance(tv, trav_l, trav_r, lref, rref, stack);
+}
+
+// Visit of a FRINGE record (at least one leaf child).
+template <bool COUNT>
+__device__ __forceinline__ void trav_step_fringe(Trav &tv, const NodeSrc &ns, buf_rsrc tris, V3 o, V3 d,
+                                                 V3 inv, uint32_t *stack, TravStats &ts) {
+    f4v q0, q1, q2, q3;
+    fetch_node(ns, tv.node, q0, q1, q2, q3);
+    const int lref = (int)__float_as_uint(q3.x), rref = (int)__float_as_uint(q3.y);
+    const bool leaf_l = lref < 0, leaf_r = rref < 0;
+    if (COUNT) { ts.n_iters++; ts.n_tri += (leaf_l ? 1u : 0u) + (leaf_r ? 1u : 0u); ts.n_box += (leaf_l ? 0u : 1u) + (leaf_r ? 0u : 1u); }
+
+    // ---- both child boxes; a leaf child's slot holds a box too, its result is ignored ------------------------------
+    float e_l, m_l, e_r, m_r;
+    box_pair(q0, q1, q2, o, inv, e_l, m_l, e_r, m_r);
 
     // ---- both leaf triangles in one segment ------------------------------------------------------------------------
     float t_l = 0.f, t_r = 0.f;
     bool ok_l = false, ok_r = false;          // plane not parallel, t >= tmin, inside (everything but `t <= c`)
     if (leaf_l || leaf_r) {
         const int il = leaf_l ? ~lref : 0, ir = leaf_r ? ~rref : 0;
-        const float4 al = tris[3 * il + 0], ar = tris[3 * ir + 0];
-        const float4 bl = tris[3 * il + 1], br = tris[3 * ir + 1];
-        const float4 cl = tris[3 * il + 2], cr = tris[3 * ir + 2];
+        const uint32_t ol = (uint32_t)il * 48u, orr = (uint32_t)ir * 48u;
+        const f4v al = buf_load16(tris, ol), ar = buf_load16(tris, orr);
+        const f4v bl = buf_load16(tris, ol + 16u), br = buf_load16(tris, orr + 16u);
+        const f4v cl = buf_load16(tris, ol + 32u), cr = buf_load16(tris, orr + 32u);
         const f2 nx = mk2(al.x, ar.x), ny = mk2(al.y, ar.y), nz = mk2(al.z, ar.z), D = mk2(al.w, ar.w);
         const f2 denom = nx * d.x + ny * d.y + nz * d.z;                      // dot(normal, dir), tri.cu:9
         const f2 num = D - (nx * o.x + ny * o.y + nz * o.z);                  // D - dot(normal, origin), tri.cu:17
@@ -332,13 +399,7 @@ __device__ __forceinline__ void trav_step(Trav &tv, const float4 *__restrict__ n
     if (leaf_r) { trav_r = false; if (ok_r && t_r <= c) { c = t_r; tv.hit = ~rref; } }
     else trav_r = !(fminf(c, m_r) <= e_r);
     tv.c = c;
-    if (!trav_l && !trav_r) {
-        if (tv.sp == 0) tv.node = -1;
-        else { tv.sp--; tv.node = (int)stack[tv.sp * 64]; }
-    } else {
-        tv.node = trav_l ? lref : rref;
-        if (trav_l && trav_r) { stack[tv.sp * 64] = (uint32_t)rref; tv.sp++; }
-    }
+    trav_advance(tv, trav_l, trav_r, lref, rref, stack);
 }
 
 }  // namespace srt

@@ -312,18 +312,31 @@ int flatten_scene(const srt_scene &s, FlatScene &out) {
         o[10] = bits_to_float(flags);
     }
 
-    // internal nodes in depth-first pre-order (left subtree adjacent to its parent, matching the left-first
-    // descent of bvh::hit); record index of node k = rank among internal nodes.
+    // Record order: first the INNER records (both children internal) in breadth-first order from the root -- the top of
+    // the tree is a prefix that the kernel keeps in LDS -- then the FRINGE records (at least one leaf child) in depth-first
+    // order.  `record index >= n_inner` tells the kernel that a visit includes triangle tests.
     std::vector<int32_t> rec_index(s.nodes.size(), -1);
     std::vector<int32_t> pre;
+    auto is_internal = [&](int32_t k) { return s.nodes[k].prim < 0; };
+    auto is_inner = [&](int32_t k) { return is_internal(k) && is_internal(s.nodes[k].left) && is_internal(s.nodes[k].right); };
+    {
+        std::vector<int32_t> queue;
+        if (is_internal(s.root)) queue.push_back(s.root);
+        for (size_t h = 0; h < queue.size(); h++) {
+            const int32_t k = queue[h];
+            if (is_inner(k)) { rec_index[k] = (int32_t)pre.size(); pre.push_back(k); }
+            if (is_internal(s.nodes[k].left)) queue.push_back(s.nodes[k].left);
+            if (is_internal(s.nodes[k].right)) queue.push_back(s.nodes[k].right);
+        }
+    }
+    out.n_inner = (int)pre.size();
     {
         std::vector<int32_t> st;
         st.push_back(s.root);
         while (!st.empty()) {
             int32_t k = st.back(); st.pop_back();
-            if (s.nodes[k].prim >= 0) continue;
-            rec_index[k] = (int32_t)pre.size();
-            pre.push_back(k);
+            if (!is_internal(k)) continue;
+            if (!is_inner(k)) { rec_index[k] = (int32_t)pre.size(); pre.push_back(k); }
             st.push_back(s.nodes[k].right);
             st.push_back(s.nodes[k].left);
         }
@@ -340,6 +353,7 @@ int flatten_scene(const srt_scene &s, FlatScene &out) {
         o[13] = bits_to_float((uint32_t)child_ref(nd.right));
     }
     out.root_ref = child_ref(s.root);
+    out.n_records = (int)pre.size();
     out.stack_depth = std::max(1, s.depth);
 
     // spectra as (s[k], s[k+1]) pairs; material scalars

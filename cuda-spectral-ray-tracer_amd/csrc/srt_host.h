@@ -80,6 +80,8 @@ struct FlatScene {
     std::vector<float> bg_sd;    // 192 floats
     int root_ref = 0;
     int stack_depth = 1;
+    int n_inner = 0;             // records [0, n_inner) have two internal children (BFS order); the rest have a leaf child
+    int n_records = 0;
 };
 int flatten_scene(const srt_scene &s, FlatScene &out);
 void cmf_rows(float *rows96x4);   // { x_bar, y_bar, z_bar, D65n } per 5 nm sample

@@ -21,7 +21,11 @@ struct RenderParams {
     const float4 *cmf;         // 96 rows (95 used): { x_bar, y_bar, z_bar, D65n }
     int root_ref;              // >= 0 record index, < 0: ~triangle (single-leaf tree)
     int stack_depth;           // LDS stack entries per lane
+    int n_inner;               // records below this index have two internal children (box tests only)
+    int n_cached;              // records below this index are resident in LDS (top of the tree)
+    int n_records;             // number of paired-child records
     uint32_t n_materials;
+    uint32_t n_tris;
     // camera_data (rendering/rendering.cuh:28-36)
     float du[3], dv[3], p00[3];
     float defocus_angle;
@@ -35,6 +39,7 @@ struct RenderParams {
     uint32_t tiles_local;                 // number of tiles this rank owns (pixel queue length / 64)
     uint32_t *pixel_counter;              // device word, zeroed before the launch: head of the pixel queue
     uint32_t shade_threshold;             // traversal phase yields to shading once this many lanes wait
+    uint32_t fringe_threshold;            // lanes at fringe records wait until this many of them can share a triangle step
     const uint32_t *tile_order;           // optional: queue slot -> local tile (cost-descending order); null = identity
     uint32_t *tile_cost;                  // probe mode: per local tile, node records visited by its pixels
     uint32_t waves_per_cu_override;       // 0 = occupancy API
@@ -61,6 +66,7 @@ hipError_t launch_unswizzle(const float *const src[3], float *const dst[3], uint
                             uint32_t image_height, hipStream_t st);
 hipError_t launch_trace(const RenderParams &p, const float *rays, size_t n, float *out, hipStream_t st);
 hipError_t launch_op_sweep(int which, const float *a, const float *b, size_t n, float *out, hipStream_t st);
-size_t render_lds_bytes(int stack_depth);
+size_t render_lds_bytes(int stack_depth, int waves_per_block, int n_cached);
+void render_launch_shape(int stack_depth, int n_records, int &waves_per_block, int &n_cached);
 
 }  // namespace srt

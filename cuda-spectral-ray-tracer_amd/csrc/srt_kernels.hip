@@ -16,12 +16,28 @@
 
 namespace srt {
 
-// LDS map (bytes): [0, 1536) colour matching rows (96 float4) | [1536, 2304) background pairs
-// (96 float2) | [2304, ...) traversal stack, stack_depth * 64 lanes * 4 B.
+// LDS map of one workgroup (W waves): [0, 1536) colour matching rows (96 float4) | [1536, 2304) background pairs
+// (96 float2) | node cache, n_cached * 64 B (top of the BVH, breadth-first) | W traversal stacks, each
+// stack_depth * 64 lanes * 4 B (lane-interleaved).
 constexpr int kLdsCmfF4 = 96;
 constexpr int kLdsBgF2 = 96;
-size_t render_lds_bytes(int stack_depth) {
-    return (size_t)kLdsCmfF4 * 16 + (size_t)kLdsBgF2 * 8 + (size_t)(stack_depth < 1 ? 1 : stack_depth) * 64 * 4;
+constexpr int kLdsTablesF4 = kLdsCmfF4 + kLdsBgF2 / 2;
+constexpr size_t kLdsBudget = 160 * 1024;
+size_t render_lds_bytes(int stack_depth, int waves_per_block, int n_cached) {
+    return (size_t)kLdsTablesF4 * 16 + (size_t)n_cached * 64 + (size_t)waves_per_block * (size_t)(stack_depth < 1 ? 1 : stack_depth) * 64 * 4;
+}
+// One workgroup per CU when the stacks leave room for a useful node cache: 16 waves share the cache.  Deep trees
+// (big stacks) fall back to smaller groups.
+void render_launch_shape(int stack_depth, int n_records, int &waves_per_block, int &n_cached) {
+    const size_t stack = (size_t)(stack_depth < 1 ? 1 : stack_depth) * 256;
+    waves_per_block = 16;
+    while (waves_per_block > 1 && (size_t)kLdsTablesF4 * 16 + waves_per_block * stack + 16 * 1024 > kLdsBudget) waves_per_block /= 2;
+    const size_t blocks_per_cu = 16 / waves_per_block;
+    const size_t per_block = kLdsBudget / blocks_per_cu;
+    const size_t fixed = (size_t)kLdsTablesF4 * 16 + waves_per_block * stack;
+    size_t room = per_block > fixed ? (per_block - fixed) / 64 : 0;
+    if (room > (size_t)n_records) room = (size_t)n_records;
+    n_cached = (int)room;
 }
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
@@ -64,24 +80,30 @@ __global__ void init_rng_kernel(uint32_t *rng, uint32_t n_lanes, uint64_t seed) 
 // MODE 0: production; MODE 1: instrumented (counts V / T / utilisation); MODE 2: cost probe -- renders P.spp samples per
 // pixel from a COPY of the RNG state, writes nothing but the per-tile traversal cost used to order the pixel queue.
 template <int MODE>
-__global__ __launch_bounds__(64) void render_kernel(const RenderParams P) {
+__global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
     constexpr bool COUNT = (MODE == 1);
     constexpr bool PROBE = (MODE == 2);
     constexpr bool ITERS = COUNT || PROBE;
     extern __shared__ float4 lds4[];
     float4 *s_cmf = lds4;
     float2 *s_bg = reinterpret_cast<float2 *>(lds4 + kLdsCmfF4);
-    uint32_t *s_stack = reinterpret_cast<uint32_t *>(lds4 + kLdsCmfF4 + kLdsBgF2 / 2);
-    const uint32_t lane = threadIdx.x;
+    float4 *s_nodes = lds4 + kLdsTablesF4;
+    uint32_t *s_stack = reinterpret_cast<uint32_t *>(lds4 + kLdsTablesF4 + 4 * (size_t)P.n_cached);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = threadIdx.x >> 6;
 
-    for (uint32_t k = lane; k < kLdsCmfF4; k += 64) s_cmf[k] = P.cmf[k];
-    for (uint32_t k = lane; k < kLdsBgF2; k += 64) s_bg[k] = P.bg_sd[k];
-    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < kLdsCmfF4; k += blockDim.x) s_cmf[k] = P.cmf[k];
+    for (uint32_t k = threadIdx.x; k < kLdsBgF2; k += blockDim.x) s_bg[k] = P.bg_sd[k];
+    for (uint32_t k = threadIdx.x; k < 4u * (uint32_t)P.n_cached; k += blockDim.x) s_nodes[k] = P.nodes[k];
+    __syncthreads();      // the only barrier: from here on every wave runs its own state machine
 
+    NodeSrc ns;
+    ns.global_nodes = make_rsrc(P.nodes, (uint32_t)P.n_records * 64u); ns.lds_nodes = (lds_cf4 *)s_nodes; ns.n_cached = P.n_cached;
+    const buf_rsrc tri_rsrc = make_rsrc(P.tris, P.n_tris * 48u);
     const V3 du = mk(P.du[0], P.du[1], P.du[2]), dv = mk(P.dv[0], P.dv[1], P.dv[2]);
     const V3 cam_center = mk(P.center[0], P.center[1], P.center[2]);
     const uint32_t n_local_pixels = P.tiles_local * 64u;
-    uint32_t *const my_stack = s_stack + lane;
+    uint32_t *const my_stack = s_stack + (size_t)wave * (size_t)(P.stack_depth < 1 ? 1 : P.stack_depth) * 64u + lane;
 
     // ---- lane state ---------------------------------------------------------------------------------------
     bool dead = false, have_path = false, result_ready = false, have_pixel = false;
@@ -326,16 +348,28 @@ __global__ __launch_bounds__(64) void render_kernel(const RenderParams P) {
         }
 
         // =========================== traversal phase =========================================================
+        // Two kinds of steps: INNER (record with two internal children: box tests only) and FRINGE (a leaf child:
+        // box + triangle tests, several times the cost).  Lanes that reach a fringe record wait until
+        // P.fringe_threshold of them can share one fringe step, or until no lane has inner work left.
         const unsigned long long alive_mask = __ballot(!dead);
         if (alive_mask == 0ull) break;
         for (;;) {
             const unsigned long long trav_mask = __ballot(tv.node >= 0);
             if (trav_mask == 0ull) break;
             if (__popcll(alive_mask & ~trav_mask) >= (int)P.shade_threshold) break;
-            if (COUNT) { ts.w_iters++; ts.w_alive += (uint32_t)__popcll(alive_mask); }
-            if (tv.node >= 0) {
-                trav_step<ITERS>(tv, P.nodes, P.tris, ro, rd, inv, my_stack, ts);
-                if (tv.node < 0) result_ready = true;
+            const unsigned long long fringe_mask = __ballot(tv.node >= P.n_inner);
+            const bool do_fringe = (__popcll(fringe_mask) >= (int)P.fringe_threshold) || (fringe_mask == trav_mask);
+            if (COUNT) { ts.w_iters++; ts.w_alive += (uint32_t)__popcll(alive_mask); if (do_fringe) { ts.w_fringe++; ts.l_fringe += (uint32_t)__popcll(fringe_mask); } else ts.l_inner += (uint32_t)__popcll(trav_mask & ~fringe_mask); }
+            if (do_fringe) {
+                if (tv.node >= P.n_inner) {
+                    trav_step_fringe<ITERS>(tv, ns, tri_rsrc, ro, rd, inv, my_stack, ts);
+                    if (tv.node < 0) result_ready = true;
+                }
+            } else {
+                if (tv.node >= 0 && tv.node < P.n_inner) {
+                    trav_step_inner<ITERS>(tv, ns, ro, inv, my_stack, ts);
+                    if (tv.node < 0) result_ready = true;
+                }
             }
         }
     }
@@ -355,6 +389,9 @@ __global__ __launch_bounds__(64) void render_kernel(const RenderParams P) {
             const uint32_t nn = wave_sum(ts.n_nan);
             if (lane == 0) {
                 atomicAdd(&P.counters[6], (unsigned long long)nn);
+                atomicAdd(&P.counters[7], (unsigned long long)ts.w_fringe);
+                atomicAdd(&P.counters[8], (unsigned long long)ts.l_fringe);
+                atomicAdd(&P.counters[9], (unsigned long long)ts.l_inner);
             }
         }
     }
@@ -408,8 +445,11 @@ __global__ __launch_bounds__(64) void trace_rays_kernel(const RenderParams P, co
     Trav tv; tv.node = -1; tv.sp = 0; tv.c = kFltMax; tv.hit = -1;
     const V3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     if (active) trav_begin<false>(tv, P.tris, P.root_ref, o, d, ts);
+    NodeSrc ns;
+    ns.global_nodes = make_rsrc(P.nodes, (uint32_t)P.n_records * 64u); ns.lds_nodes = nullptr; ns.n_cached = 0;
+    const buf_rsrc tri_rsrc = make_rsrc(P.tris, P.n_tris * 48u);
     while (__ballot(tv.node >= 0) != 0ull) {
-        if (tv.node >= 0) trav_step<false>(tv, P.nodes, P.tris, o, d, inv, s_stack + lane, ts);
+        if (tv.node >= 0) trav_step_fringe<false>(tv, ns, tri_rsrc, o, d, inv, s_stack + lane, ts);   // handles inner records too
     }
     const float t = tv.c;
     const int tri = tv.hit;
@@ -467,17 +507,26 @@ hipError_t launch_init_rng(uint32_t *rng, uint32_t n_lanes, uint64_t seed, hipSt
 }
 
 template <int MODE>
-static hipError_t launch_render_mode(const RenderParams &p, uint32_t n_cu, hipStream_t st) {
-    const size_t lds = render_lds_bytes(p.stack_depth);
-    // persistent waves: as many 1-wave workgroups as the chip holds at this kernel's occupancy, never more than tiles
-    int per_cu = 0;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_kernel<MODE>, 64, lds);
-    if (e != hipSuccess || per_cu <= 0) { (void)hipGetLastError(); per_cu = 16; }
-    if (per_cu > 32) per_cu = 32;
-    if (p.waves_per_cu_override > 0) per_cu = (int)p.waves_per_cu_override;
-    uint32_t n_waves = n_cu * (uint32_t)per_cu;
+static hipError_t launch_render_mode(const RenderParams &p_in, uint32_t n_cu, hipStream_t st) {
+    RenderParams p = p_in;
+    int wpb = 1, n_cached = 0;
+    render_launch_shape(p.stack_depth, p.n_records, wpb, n_cached);
+    if (p.waves_per_cu_override > 0 && p.waves_per_cu_override < 16) {   // experiment knob: smaller groups, no cache sharing
+        wpb = 1; n_cached = 0;
+    }
+    p.n_cached = n_cached;
+    const size_t lds = render_lds_bytes(p.stack_depth, wpb, n_cached);
+    static bool attr_set[3] = {false, false, false};
+    if (!attr_set[MODE]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget);
+        attr_set[MODE] = true;
+    }
+    // persistent waves: fill every CU (16 waves per CU at this kernel's register budget), never more waves than tiles
+    uint32_t waves_per_cu = p.waves_per_cu_override > 0 ? p.waves_per_cu_override : 16u;
+    uint32_t n_waves = n_cu * waves_per_cu;
     if (n_waves > p.tiles_local) n_waves = p.tiles_local;
-    hipLaunchKernelGGL(render_kernel<MODE>, dim3(n_waves), dim3(64), lds, st, p);
+    const uint32_t n_blocks = (n_waves + (uint32_t)wpb - 1) / (uint32_t)wpb;
+    hipLaunchKernelGGL(render_kernel<MODE>, dim3(n_blocks), dim3(64 * wpb), lds, st, p);
     return hipGetLastError();
 }
 

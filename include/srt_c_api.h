@@ -81,7 +81,8 @@ typedef struct {
     uint64_t box_tests;
     /* instrumented kernel only: [0] wave-level traversal steps, [1] sum over those steps of lanes that still own
      * work, [2] closest-hit queries answered without traversal because the direction is NaN (the reference walks
-     * the whole tree for them and finds nothing).  SIMD utilisation of traversal =
+     * the whole tree for them and finds nothing), [3] fringe steps, [4] lanes served by them, [5] lanes served by
+     * inner steps.  SIMD utilisation of traversal =
      * node_visits / (64 * util[0]).  node_visits / tri_tests / box_tests count the work actually done. */
     uint64_t util[7];
     uint64_t reserved[4];
