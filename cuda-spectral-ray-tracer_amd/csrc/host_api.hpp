@@ -39,6 +39,11 @@ public:
         srt_camera_init(w, h, _vfov, _lookfrom.e, _lookat.e, _vup.e, _da, _fd, &data);   // camera::initialize, camera.cu:7-58
         num_pixels = (uint)(w * h);
     }
+    // camera whose derived quantities were already computed (e.g. by srt_scene_default_camera)
+    static camera fromData(const srt_camera_data &d, float ar = 1.f) {
+        camera c; c.aspect_ratio = ar; c.image_width = (int)d.width; c.image_height = (int)d.height; c.num_pixels = d.width * d.height; c.data = d;
+        return c;
+    }
     const int &getImageWidth() const { return image_width; }
     const int &getImageHeight() const { return image_height; }
     const uint &getNumPixels() const { return num_pixels; }
@@ -161,6 +166,7 @@ public:
     const float *getDevFBg() const { return plane(1); }
     const float *getDevFBb() const { return plane(2); }
     srt_ctx *getContext() const { return ctx; }
+    bool isDeviceInited() const { return device_inited; }
 private:
     void call_render_kernel(uint width, uint height, uint offset_x, uint offset_y) {   // rendering.cu:244-277
         if (!device_inited) { std::cerr << "Device parameters were not initialized, render aborted" << std::endl; return; }
@@ -209,7 +215,7 @@ public:
         uint y_chunks = (uint)std::ceil(float(image_height) / float(chunk_height));
         n_iterations = x_chunks * y_chunks;
         r.init_device_params(threads, blocks, chunk_width, chunk_height);
-        device_inited = true;
+        device_inited = r.isDeviceInited();   // reference sets true unconditionally; here a missing GPU must not look ready
     }
     void init_device_params(uint _chunk_width, uint _chunk_height) {   // render_manager.cu:91-102
         if (!renderer_inited) { std::cerr << "Init renderer before assigning device parameters" << std::endl; return; }
@@ -230,6 +236,8 @@ public:
         r.render(last_chunk_width, last_chunk_height, offset_x, offset_y);
         // the device framebuffer holds this chunk until the next render(): un-swizzle it into fb now
         srt_read_fb_rowmajor(r.getContext(), fb->r, fb->g, fb->b, image_width, image_height);
+        srt_stats st;
+        if (srt_get_stats(r.getContext(), &st) == SRT_OK) total_rays += st.rays;
         bool last_step = false;
         i++;
         if (i == n_iterations) { rd->is_last = true; last_step = true; }
@@ -247,6 +255,7 @@ public:
         return !last_read;
     }
     bool isDone() const { return done; }
+    uint64_t getTotalRays() const { return total_rays; }   // closest-hit queries of all chunks rendered so far
     uint getImWidth() const { return image_width; }
     uint getImHeight() const { return image_height; }
     bool isReadyToRender() const { return device_inited && i < n_iterations; }
@@ -264,6 +273,7 @@ private:
     size_t next_write_render_data_index = 0, next_read_render_data_index = 0;
     uint i = 0, chunk_width = 0, chunk_height = 0, n_iterations = 0, x_chunks = 1;
     uint offset_x = 0, offset_y = 0, last_chunk_width = 0, last_chunk_height = 0;
+    uint64_t total_rays = 0;
     std::thread render_worker;
     dim3 threads, blocks;
 };

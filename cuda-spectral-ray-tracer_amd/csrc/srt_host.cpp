@@ -772,8 +772,8 @@ static void scene_random_spheres(srt_scene &s, uint64_t seed) {
 }
 
 static void scene_mesh100k(srt_scene &s, uint64_t seed) {
-    // Cornell shell + a 81 920-triangle icosphere (subdivision 6, dielectric) + a displaced 96x96 floor grid
-    // (18 432 triangles, lambertian): 100 364 triangles in total.
+    // Cornell shell + a 81 920-triangle icosphere (subdivision 6, dielectric) + a metal octahedron + a displaced 96x96
+    // floor grid (18 432 triangles, lambertian): 100 372 triangles in total.
     SplitMix rng(seed ? seed : 0x100c0ffeeull);
     s.mats.clear();
     s.mats.push_back(make_material(SRT_MAT_LAMBERTIAN, .73f, .73f, .73f, 1.f, 0.f));
@@ -785,7 +785,8 @@ static void scene_mesh100k(srt_scene &s, uint64_t seed) {
     Builder B(s);
     const uint32_t walls[5] = {0, 0, 0, 0, 0};
     cornell_walls_and_light(B, walls, 1);
-    add_icosphere(B, f3(340.f, 200.f, 330.f), 120.f, 6, 4);
+    add_icosphere(B, f3(340.f, 200.f, 330.f), 120.f, 6, 2);      // the dielectric object (flint glass, Q1 applies)
+    add_octahedron(B, f3(140.f, 120.f, 160.f), 70.f, 4);          // a small metal object
     const int G = 96;
     std::vector<float> hgt((G + 1) * (G + 1));
     for (auto &h : hgt) h = 4.f + 22.f * rng.uni();

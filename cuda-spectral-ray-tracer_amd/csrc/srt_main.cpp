@@ -1,0 +1,200 @@
+// srt_main.cpp -- command-line driver with the reference's flag names, log keys and output conventions
+// (SURVEY 8(f) rows f2/f3): main.cpp:135-167, io/params.h:236-304, _log_/log_context.cpp:5-65,
+// io/save_image.cpp:8-20 + image/image.cpp:3-18 (CImg replaced by a 30-line BMP writer).
+//
+//   srt_render -s 1 -xr 600 -ar 16/9 -ns 500 -bl 10 -xc 0 -yc 0 -t "my title" --save --do-log [--gpu N] [--sah]
+//
+// Scene ids 0/1/2 are the reference's CORNELL/PRISM/TRIS (io/params.h:15-19); 100/101 are this build's
+// synthetic benchmark scenes.  There is no window (--no-show is accepted and is the only mode).
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <filesystem>
+#include <fstream>
+#include <iomanip>
+#include <iostream>
+#include <limits>
+#include <map>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "host_api.hpp"
+
+namespace fs = std::filesystem;
+using namespace srt_host;
+
+namespace {
+
+const char *kSceneNames[] = {"Cornell Box", "Prism World", "Different Materials"};   // io/params.h:19
+
+struct parameters {   // io/params.h:21-223
+    std::string image_title, log_subdir;
+    uint scene = 0, xres = 600, yres = 600;
+    float ar = 1.0f;
+    uint xcsize = 0, ycsize = 0, n_samples = 500, bounce_limit = 10;
+    bool do_log = false, show_render = true, do_save = false;
+    int gpu = 0;
+    bool sah = false;
+
+    void resetYres() { yres = static_cast<uint>(xres / ar); yres = (yres < 1) ? 1 : yres; }   // params.h:176-180
+    uint getXcsize() const { uint r = xcsize == 0 ? ycsize : xcsize; return r == 0 ? xres : r; }   // :53-57
+    uint getYcsize() const { uint r = ycsize == 0 ? xcsize : ycsize; return r == 0 ? yres : r; }   // :59-63
+    std::string getImgTitle() const {
+        if (!image_title.empty()) return image_title;
+        return scene < 3 ? std::string(kSceneNames[scene]) : ("Scene " + std::to_string(scene));
+    }
+};
+
+float parseAR(const std::string &s) {   // params.h:182-195
+    std::stringstream ss(s);
+    std::string num;
+    std::getline(ss, num, '/');
+    float ar = std::stof(num);
+    if (std::getline(ss, num, '/')) ar /= std::stof(num);
+    return ar;
+}
+
+bool parseArgs(int argc, char **argv, parameters &p) {   // params.h:236-304
+    for (int i = 1; i < argc; i++) {
+        const std::string arg(argv[i]);
+        const bool is_last = i + 1 == argc;
+        try {
+            if (!is_last && (arg == "-t" || arg == "--title")) p.image_title = argv[++i];
+            else if (!is_last && (arg == "-lsub" || arg == "--log-subdir")) p.log_subdir = argv[++i];
+            else if (!is_last && (arg == "-s" || arg == "--scene")) p.scene = (uint)std::stoul(argv[++i]);
+            else if (!is_last && (arg == "-xr" || arg == "--xres")) { p.xres = (uint)std::stoul(argv[++i]); p.resetYres(); }
+            else if (!is_last && (arg == "-ar" || arg == "--aspect-ratio")) { p.ar = parseAR(argv[++i]); p.resetYres(); }
+            else if (!is_last && (arg == "-xc" || arg == "--xcsize")) p.xcsize = (uint)std::stoul(argv[++i]);
+            else if (!is_last && (arg == "-yc" || arg == "--ycsize")) p.ycsize = (uint)std::stoul(argv[++i]);
+            else if (!is_last && (arg == "-ns" || arg == "--nsamples")) p.n_samples = (uint)std::stoul(argv[++i]);
+            else if (!is_last && (arg == "-bl" || arg == "--bounce-limit")) p.bounce_limit = (uint)std::stoul(argv[++i]);
+            else if (!is_last && arg == "--gpu") p.gpu = std::stoi(argv[++i]);
+            else if (arg == "--sah") p.sah = true;
+            else if (arg == "--do-log") p.do_log = true;
+            else if (arg == "--no-show") p.show_render = false;
+            else if (arg == "--save") p.do_save = true;
+            else std::cout << "Unkown argument name: " << arg << std::endl;
+        } catch (...) {
+            std::cerr << "Error while parsing " << arg << " arg value, keeping previous (default most likely) value" << std::endl;
+        }
+    }
+    return true;
+}
+
+void string_to_filename(std::string &str) {   // utils/utility.h:32-41
+    for (char &c : str) c = (c == ' ') ? '_' : (char)std::tolower(static_cast<unsigned char>(c));
+}
+
+// _log_/log_context.{h,cpp}: ordered key: value lines -> logs/[subdir/]<epoch_ms>_<title>_log.txt
+struct log_context {
+    std::vector<std::string> order;
+    std::map<std::string, std::string> data;
+    std::string title, subdir;
+    void add_entry(const std::string &name, const std::string &value) { order.push_back(name); data[name] = value; }
+    template <typename T> void add_entry(const std::string &name, T value) {
+        std::ostringstream oss;
+        if constexpr (std::is_floating_point<T>::value) oss << std::setprecision(std::numeric_limits<T>::digits10 + 1);
+        oss << value;
+        add_entry(name, oss.str());
+    }
+    void to_file() const {
+        fs::path dir = fs::path("logs") / subdir;
+        fs::create_directories(dir);
+        const auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::system_clock::now().time_since_epoch()).count();
+        std::string name = std::to_string(ms) + "_" + title + "_log.txt";
+        string_to_filename(name);
+        const fs::path file = dir / name;
+        std::ofstream out(file);
+        if (!out.is_open()) { std::cerr << "Failed to save log file at: " << file.string() << std::endl; return; }
+        for (const auto &k : order) out << k << ": " << data.at(k) << "\n";
+        std::clog << "Log file saved successfully at: " << file.string() << std::endl;
+    }
+};
+
+// io/save_image.cpp:8-20 (renders/<file>), image/image.cpp:3-18: 24-bit BMP, bottom-up rows, BGR
+bool save_img(const image_channels &ch, uint width, uint height, const std::string &filename) {
+    const fs::path p = fs::path("renders") / filename;
+    fs::create_directories(p.parent_path());
+    const uint32_t row = (width * 3 + 3) & ~3u, size = 54 + row * height;
+    std::vector<unsigned char> buf(size, 0);
+    auto put32 = [&](size_t off, uint32_t v) { buf[off] = v & 255; buf[off + 1] = (v >> 8) & 255; buf[off + 2] = (v >> 16) & 255; buf[off + 3] = (v >> 24) & 255; };
+    buf[0] = 'B'; buf[1] = 'M';
+    put32(2, size); put32(10, 54); put32(14, 40); put32(18, width); put32(22, height);
+    buf[26] = 1; buf[28] = 24; put32(34, row * height);
+    for (uint y = 0; y < height; y++)
+        for (uint x = 0; x < width; x++) {
+            unsigned char *px = &buf[54 + (size_t)(height - 1 - y) * row + 3 * (size_t)x];
+            const size_t k = (size_t)y * width + x;
+            px[0] = ch.b[k]; px[1] = ch.g[k]; px[2] = ch.r[k];
+        }
+    std::ofstream out(p, std::ios::binary);
+    if (!out.is_open()) return false;
+    out.write(reinterpret_cast<const char *>(buf.data()), (std::streamsize)buf.size());
+    std::clog << "Image saved as: " << p.filename() << std::endl;
+    return true;
+}
+
+}  // namespace
+
+int main(int argc, char **argv) {
+    parameters pm;
+    parseArgs(argc, argv, pm);
+    std::cout << "Image Title: " << pm.getImgTitle() << std::endl;
+    if (!pm.log_subdir.empty()) std::cout << "Log Subdir: " << pm.log_subdir << std::endl;
+    std::cout << "Scene: " << (pm.scene < 3 ? kSceneNames[pm.scene] : "synthetic") << " (ID: " << pm.scene << ")" << std::endl;
+    std::cout << "X res: " << pm.xres << "\nY res: " << pm.yres << "\nAR: " << pm.ar << std::endl;
+    std::cout << "X chunk size: " << pm.getXcsize() << "\nY chunk size: " << pm.getYcsize() << std::endl;
+    std::cout << "# samples: " << pm.n_samples << "\n# max bounces: " << pm.bounce_limit << std::endl;
+    std::cout << "Logging " << (pm.do_log ? "enabled" : "disabled") << std::endl;
+
+    log_context lc;
+    lc.title = pm.getImgTitle(); lc.subdir = pm.log_subdir;
+
+    // render(), main.cpp:74-133
+    scene_manager sm((int)pm.scene, (int)pm.xres, (int)pm.yres, pm.sah ? SRT_BVH_SAH : SRT_BVH_REFERENCE);
+    if (!sm.isWorldInited()) { std::cerr << sm.getResultMsg() << std::endl; return 1; }
+    std::clog << sm.getResultMsg() << std::endl;
+    lc.add_entry("image width", pm.xres);                                   // scene.cu:452-453
+    lc.add_entry("image height", pm.yres);
+    lc.add_entry("scene type", std::string(pm.scene < 3 ? kSceneNames[pm.scene] : "synthetic"));   // scene.cu:419-421
+    lc.add_entry("# primitives", sm.getWorldSize());
+    lc.add_entry("# materials", sm.getNumMaterials());
+
+    frame_buffer fb((size_t)pm.xres * pm.yres);
+    image_channels ch(fb);
+    // the scene's own camera builder (scene.cu:259-320), evaluated by the library for this image size
+    camera scene_cam = camera::fromData(sm.getCameraData(), pm.ar);
+    render_manager rm(sm.getScene(), &scene_cam, &fb);
+    rm.init_renderer(pm.bounce_limit, pm.n_samples, pm.gpu);
+    lc.add_entry("samples per pixel", pm.n_samples);                        // render_manager.cu:124-126
+    lc.add_entry("bounce limit", pm.bounce_limit);
+    rm.init_device_params(pm.getXcsize(), pm.getYcsize());
+    lc.add_entry("chunk width", pm.getXcsize());                            // rendering.cu:337-349
+    lc.add_entry("chunk height", pm.getYcsize());
+    lc.add_entry("threads x", 28u); lc.add_entry("threads y", 16u); lc.add_entry("threads z", 1u);
+    lc.add_entry("blocks x", pm.getXcsize() / 28 + 1); lc.add_entry("blocks y", pm.getYcsize() / 16 + 1); lc.add_entry("blocks z", 1u);
+    if (!rm.isReadyToRender()) { std::cerr << "Device parameters not yet initialized" << std::endl; return 1; }
+
+    // render_cycle(), main.cpp:16-72 (wall clock instead of the reference's process-CPU clock())
+    std::clog << "Rendering... ";
+    const auto t0 = std::chrono::steady_clock::now();
+    rm.render_cycle();
+    bool has_data = true;
+    do { has_data = rm.update_fb(); ch = fb; } while (has_data);
+    rm.end_render();
+    const double seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    lc.add_entry("total rendering time (seconds)", seconds);
+    std::clog << "done, took " << seconds << " seconds.\n";
+    const uint64_t rays = rm.getTotalRays();
+    lc.add_entry("rays", rays);
+    lc.add_entry("Mray/s", (double)rays / seconds / 1e6);
+    lc.add_entry("Mpath/s", (double)pm.xres * pm.yres * pm.n_samples / seconds / 1e6);
+    std::clog << (double)rays / seconds / 1e6 << " Mray/s" << std::endl;
+
+    if (pm.do_log) lc.to_file();
+    std::string image_filename = pm.getImgTitle() + ".bmp";
+    string_to_filename(image_filename);
+    if (pm.do_save) save_img(ch, pm.xres, pm.yres, image_filename);
+    return 0;
+}

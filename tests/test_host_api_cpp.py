@@ -60,3 +60,29 @@ def test_render_manager_matches_oracle(srt, orc, tmp_path, chunk):
                 mask[oy:oy + h, ox:ox + w] = True
                 want[c][mask.ravel()] = img[mask.ravel()]
     assert np.array_equal(got.reshape(3, -1), want)
+
+
+@pytest.mark.gpu
+def test_cli_driver_writes_bmp_and_log(srt, orc, tmp_path):
+    """srt_render: the reference's flags (io/params.h:236-304), renders/<title>.bmp and logs/<ts>_<title>_log.txt."""
+    exe = os.path.join(PKG, "srt_render")
+    assert os.path.exists(exe)
+    subprocess.check_call([exe, "-s", "1", "-xr", "64", "-ar", "4/3", "-ns", "4", "-bl", "8", "-t", "Prism Test", "--save", "--do-log",
+                           "--no-show", "-lsub", "unit"], cwd=str(tmp_path), timeout=120)
+    bmp = tmp_path / "renders" / "prism_test.bmp"                        # string_to_filename: lower case, spaces -> _
+    raw = bmp.read_bytes()
+    assert raw[:2] == b"BM" and int.from_bytes(raw[18:22], "little") == 64 and int.from_bytes(raw[22:26], "little") == 48
+    logs = list((tmp_path / "logs" / "unit").glob("*_prism_test_log.txt"))
+    assert len(logs) == 1
+    text = logs[0].read_text()
+    for key in ("image width: 64", "image height: 48", "# primitives: 20", "# materials: 3", "samples per pixel: 4", "bounce limit: 8",
+                "chunk width: 64", "threads x: 28", "blocks y: 4", "total rendering time (seconds):", "Mray/s:"):
+        assert key in text, key
+    # pixels = the oracle's quantised framebuffer (BMP rows are bottom-up, BGR)
+    W, H = 64, 48
+    scene = srt.Scene.builtin(srt.SCENE_PRISM).build_bvh(srt.BVH_REFERENCE, 1984)
+    ref = oracle_scene_for(orc, scene, 0).render(scene.default_camera(W, H), W, H, 4, 8)
+    img = np.frombuffer(raw[54:], np.uint8).reshape(H, W * 3)[::-1].reshape(H, W, 3)
+    for c, plane in enumerate(ref["fb"]):
+        want = orc.unswizzle(plane, 28, 16, W // 28 + 1, H // 16 + 1, W, H, 0, 0, W, H).reshape(H, W).astype(np.uint8)
+        assert np.array_equal(img[:, :, 2 - c], want)
