@@ -153,7 +153,7 @@ int srt_upload_scene(srt_ctx *c, const srt_scene *s) {
     FlatScene f;
     int rc = flatten_scene(*s, f);
     if (rc != SRT_OK) return fail(c, rc, global_error());
-    if (render_lds_bytes(f.stack_depth, 1, 0) > 64 * 1024) return fail(c, SRT_ERR_BVH, "srt_upload_scene: BVH too deep for the LDS traversal stack");
+    if (render_lds_bytes(f.stack_depth, 1, 0, f.n_records) > 64 * 1024) return fail(c, SRT_ERR_BVH, "srt_upload_scene: BVH too deep for the LDS traversal stack");
     if ((rc = upload(c, &c->d_nodes, f.nodes)) != SRT_OK) return rc;
     if ((rc = upload(c, &c->d_tris, f.tris)) != SRT_OK) return rc;
     if ((rc = upload(c, &c->d_mat_sd, f.mat_sd)) != SRT_OK) return rc;
@@ -359,7 +359,7 @@ int srt_get_stats(srt_ctx *c, srt_stats *out) {
     HIP_TRY(c, hipMemcpy(h, c->d_counters, sizeof(h), hipMemcpyDeviceToHost));
     memset(out, 0, sizeof(*out));
     out->rays = h[0]; out->node_visits = h[1]; out->tri_tests = h[2]; out->box_tests = h[3];
-    for (int k = 0; k < 7; k++) out->util[k] = h[4 + k];
+    for (int k = 0; k < 9; k++) out->util[k] = h[4 + k];
     // paths = spp * pixels owned by this rank
     uint64_t pixels = 0;
     for (uint32_t t = c->rank; t < c->n_tiles; t += c->world) {

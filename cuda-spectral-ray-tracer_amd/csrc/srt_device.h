@@ -293,20 +293,49 @@ __device__ __forceinline__ f4v buf_load16(buf_rsrc r, uint32_t byte_offset) {
     return as_f4v(__builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_offset, 0, 0));
 }
 
+// LDS image of the INNER records (both children internal): three planes of float4 (the 12 box floats) and one or two
+// planes of child references -- 52 B per record when all record indices fit 16 bit (56 B otherwise) instead of the 64 B
+// global record, so that a whole ~2 300-record inner tree (cfg 3) is resident and an INNER step never leaves the CU.
+typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
 struct NodeSrc {
     buf_rsrc global_nodes;
-    lds_cf4 *lds_nodes;
+    lds_cf4 *lds_q0, *lds_q1, *lds_q2;
+    lds_cu32 *lds_r0, *lds_r1;      // refs16: r0 = lref | rref << 16; else r0 = lref, r1 = rref
     int n_cached;
+    bool refs16;
 };
-__device__ __forceinline__ void fetch_node(const NodeSrc &ns, int node, f4v &q0, f4v &q1, f4v &q2, f4v &q3) {
+__device__ __forceinline__ void fetch_node_global(const NodeSrc &ns, int node, f4v &q0, f4v &q1, f4v &q2, int &lref, int &rref) {
+    const uint32_t off = (uint32_t)node * 64u;
+    q0 = buf_load16(ns.global_nodes, off); q1 = buf_load16(ns.global_nodes, off + 16u);
+    q2 = buf_load16(ns.global_nodes, off + 32u);
+    const f4v q3 = buf_load16(ns.global_nodes, off + 48u);
+    lref = (int)__float_as_uint(q3.x); rref = (int)__float_as_uint(q3.y);
+}
+// record that may be LDS resident (inner records only)
+__device__ __forceinline__ void fetch_node(const NodeSrc &ns, int node, f4v &q0, f4v &q1, f4v &q2, int &lref, int &rref) {
     if (node < ns.n_cached) {
-        lds_cf4 *p = ns.lds_nodes + 4 * node;
-        q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3];
+        q0 = ns.lds_q0[node]; q1 = ns.lds_q1[node]; q2 = ns.lds_q2[node];
+        const uint32_t r0 = ns.lds_r0[node];
+        if (ns.refs16) { lref = (int)(r0 & 0xffffu); rref = (int)(r0 >> 16); }
+        else { lref = (int)r0; rref = (int)ns.lds_r1[node]; }
     } else {
-        const uint32_t off = (uint32_t)node * 64u;
-        q0 = buf_load16(ns.global_nodes, off); q1 = buf_load16(ns.global_nodes, off + 16u);
-        q2 = buf_load16(ns.global_nodes, off + 32u); q3 = buf_load16(ns.global_nodes, off + 48u);
+        fetch_node_global(ns, node, q0, q1, q2, lref, rref);
     }
+}
+
+// Traversal stack: this lane's column, element k at index k*64; 16-bit entries when every record index fits.
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+typedef __attribute__((address_space(3))) uint16_t lds_u16;
+struct StackRef {
+    lds_u32 *s32;      // used when !narrow
+    lds_u16 *s16;      // used when narrow
+    bool narrow;
+};
+__device__ __forceinline__ void stack_push(const StackRef &st, int sp, int ref) {
+    if (st.narrow) st.s16[sp * 64] = (uint16_t)ref; else st.s32[sp * 64] = (uint32_t)ref;
+}
+__device__ __forceinline__ int stack_pop(const StackRef &st, int sp) {
+    return st.narrow ? (int)st.s16[sp * 64] : (int)st.s32[sp * 64];
 }
 
 // c-independent part of both slab tests (x = left child, y = right child), packed fp32.
@@ -322,22 +351,22 @@ __device__ __forceinline__ void box_pair(const f4v &q0, const f4v &q1, const f4v
     m_l = fminf(fminf(t1x.x, t1y.x), t1z.x); m_r = fminf(fminf(t1x.y, t1y.y), t1z.y);
 }
 
-__device__ __forceinline__ void trav_advance(Trav &tv, bool trav_l, bool trav_r, int lref, int rref, uint32_t *stack) {
+__device__ __forceinline__ void trav_advance(Trav &tv, bool trav_l, bool trav_r, int lref, int rref, const StackRef &stack) {
     if (!trav_l && !trav_r) {                       // bvh.cu:154-155: pop
         if (tv.sp == 0) tv.node = -1;
-        else { tv.sp--; tv.node = (int)stack[tv.sp * 64]; }
+        else { tv.sp--; tv.node = stack_pop(stack, tv.sp); }
     } else {                                        // bvh.cu:156-160: descend left first, push right iff both
         tv.node = trav_l ? lref : rref;
-        if (trav_l && trav_r) { stack[tv.sp * 64] = (uint32_t)rref; tv.sp++; }
+        if (trav_l && trav_r) { stack_push(stack, tv.sp, rref); tv.sp++; }
     }
 }
 
 // Visit of an INNER record (both children internal): two box tests, no triangle work.
 template <bool COUNT>
-__device__ __forceinline__ void trav_step_inner(Trav &tv, const NodeSrc &ns, V3 o, V3 inv, uint32_t *stack, TravStats &ts) {
-    f4v q0, q1, q2, q3;
-    fetch_node(ns, tv.node, q0, q1, q2, q3);
-    const int lref = (int)__float_as_uint(q3.x), rref = (int)__float_as_uint(q3.y);
+__device__ __forceinline__ void trav_step_inner(Trav &tv, const NodeSrc &ns, V3 o, V3 inv, const StackRef &stack, TravStats &ts) {
+    f4v q0, q1, q2;
+    int lref, rref;
+    fetch_node(ns, tv.node, q0, q1, q2, lref, rref);
     if (COUNT) { ts.n_iters++; ts.n_box += 2u; }
     float e_l, m_l, e_r, m_r;
     box_pair(q0, q1, q2, o, inv, e_l, m_l, e_r, m_r);
@@ -350,10 +379,10 @@ __device__ __forceinline__ void trav_step_inner(Trav &tv, const NodeSrc &ns, V3 
 // Visit of a FRINGE record (at least one leaf child).
 template <bool COUNT>
 __device__ __forceinline__ void trav_step_fringe(Trav &tv, const NodeSrc &ns, buf_rsrc tris, V3 o, V3 d,
-                                                 V3 inv, uint32_t *stack, TravStats &ts) {
-    f4v q0, q1, q2, q3;
-    fetch_node(ns, tv.node, q0, q1, q2, q3);
-    const int lref = (int)__float_as_uint(q3.x), rref = (int)__float_as_uint(q3.y);
+                                                 V3 inv, const StackRef &stack, TravStats &ts) {
+    f4v q0, q1, q2;
+    int lref, rref;
+    fetch_node_global(ns, tv.node, q0, q1, q2, lref, rref);      // fringe records are never LDS resident
     const bool leaf_l = lref < 0, leaf_r = rref < 0;
     if (COUNT) { ts.n_iters++; ts.n_tri += (leaf_l ? 1u : 0u) + (leaf_r ? 1u : 0u); ts.n_box += (leaf_l ? 0u : 1u) + (leaf_r ? 0u : 1u); }
 

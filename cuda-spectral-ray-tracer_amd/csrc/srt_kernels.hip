@@ -17,26 +17,30 @@
 namespace srt {
 
 // LDS map of one workgroup (W waves): [0, 1536) colour matching rows (96 float4) | [1536, 2304) background pairs
-// (96 float2) | node cache, n_cached * 64 B (top of the BVH, breadth-first) | W traversal stacks, each
-// stack_depth * 64 lanes * 4 B (lane-interleaved).
+// (96 float2) | inner-record cache: three float4 planes + one (16-bit refs) or two u32 planes of n_cached entries |
+// W traversal stacks, each stack_depth * 64 lanes * (2 or 4) B, lane-interleaved.
 constexpr int kLdsCmfF4 = 96;
 constexpr int kLdsBgF2 = 96;
 constexpr int kLdsTablesF4 = kLdsCmfF4 + kLdsBgF2 / 2;
 constexpr size_t kLdsBudget = 160 * 1024;
-size_t render_lds_bytes(int stack_depth, int waves_per_block, int n_cached) {
-    return (size_t)kLdsTablesF4 * 16 + (size_t)n_cached * 64 + (size_t)waves_per_block * (size_t)(stack_depth < 1 ? 1 : stack_depth) * 64 * 4;
+static inline size_t round16(size_t v) { return (v + 15) & ~(size_t)15; }
+static inline bool narrow_refs(int n_records) { return n_records <= 65535; }
+static inline size_t cache_bytes(int n_cached, int n_records) { return round16((size_t)n_cached * (narrow_refs(n_records) ? 52 : 56)); }
+static inline size_t stack_bytes(int stack_depth, int n_records) { return (size_t)(stack_depth < 1 ? 1 : stack_depth) * 64 * (narrow_refs(n_records) ? 2 : 4); }
+size_t render_lds_bytes(int stack_depth, int waves_per_block, int n_cached, int n_records) {
+    return (size_t)kLdsTablesF4 * 16 + cache_bytes(n_cached, n_records) + (size_t)waves_per_block * stack_bytes(stack_depth, n_records);
 }
-// One workgroup per CU when the stacks leave room for a useful node cache: 16 waves share the cache.  Deep trees
-// (big stacks) fall back to smaller groups.
-void render_launch_shape(int stack_depth, int n_records, int &waves_per_block, int &n_cached) {
-    const size_t stack = (size_t)(stack_depth < 1 ? 1 : stack_depth) * 256;
+// One workgroup per CU when the stacks leave room for a useful cache: 16 waves share it.  Deep trees (big stacks)
+// fall back to smaller groups.  Only INNER records are cached (n_inner of them, breadth-first order).
+void render_launch_shape(int stack_depth, int n_records, int n_inner, int &waves_per_block, int &n_cached) {
+    const size_t stack = stack_bytes(stack_depth, n_records);
     waves_per_block = 16;
     while (waves_per_block > 1 && (size_t)kLdsTablesF4 * 16 + waves_per_block * stack + 16 * 1024 > kLdsBudget) waves_per_block /= 2;
     const size_t blocks_per_cu = 16 / waves_per_block;
     const size_t per_block = kLdsBudget / blocks_per_cu;
-    const size_t fixed = (size_t)kLdsTablesF4 * 16 + waves_per_block * stack;
-    size_t room = per_block > fixed ? (per_block - fixed) / 64 : 0;
-    if (room > (size_t)n_records) room = (size_t)n_records;
+    const size_t fixed = (size_t)kLdsTablesF4 * 16 + waves_per_block * stack + 64;
+    size_t room = per_block > fixed ? (per_block - fixed) / (narrow_refs(n_records) ? 52 : 56) : 0;
+    if (room > (size_t)n_inner) room = (size_t)n_inner;
     n_cached = (int)room;
 }
 
@@ -87,23 +91,42 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
     extern __shared__ float4 lds4[];
     float4 *s_cmf = lds4;
     float2 *s_bg = reinterpret_cast<float2 *>(lds4 + kLdsCmfF4);
-    float4 *s_nodes = lds4 + kLdsTablesF4;
-    uint32_t *s_stack = reinterpret_cast<uint32_t *>(lds4 + kLdsTablesF4 + 4 * (size_t)P.n_cached);
+    const bool narrow = P.n_records <= 65535;
+    const uint32_t nc = (uint32_t)P.n_cached;
+    float4 *s_q0 = lds4 + kLdsTablesF4, *s_q1 = s_q0 + nc, *s_q2 = s_q1 + nc;
+    uint32_t *s_r0 = reinterpret_cast<uint32_t *>(s_q2 + nc), *s_r1 = s_r0 + nc;
+    const size_t cache_b = (((size_t)nc * (narrow ? 52u : 56u)) + 15u) & ~(size_t)15u;
+    char *s_stack_base = reinterpret_cast<char *>(lds4 + kLdsTablesF4) + cache_b;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
 
     for (uint32_t k = threadIdx.x; k < kLdsCmfF4; k += blockDim.x) s_cmf[k] = P.cmf[k];
     for (uint32_t k = threadIdx.x; k < kLdsBgF2; k += blockDim.x) s_bg[k] = P.bg_sd[k];
-    for (uint32_t k = threadIdx.x; k < 4u * (uint32_t)P.n_cached; k += blockDim.x) s_nodes[k] = P.nodes[k];
+    for (uint32_t k = threadIdx.x; k < nc; k += blockDim.x) {
+        s_q0[k] = P.nodes[4 * k + 0]; s_q1[k] = P.nodes[4 * k + 1]; s_q2[k] = P.nodes[4 * k + 2];
+        const float4 q3 = P.nodes[4 * k + 3];
+        const uint32_t lr = __float_as_uint(q3.x), rr = __float_as_uint(q3.y);
+        if (narrow) s_r0[k] = (lr & 0xffffu) | (rr << 16);
+        else { s_r0[k] = lr; s_r1[k] = rr; }
+    }
     __syncthreads();      // the only barrier: from here on every wave runs its own state machine
 
     NodeSrc ns;
-    ns.global_nodes = make_rsrc(P.nodes, (uint32_t)P.n_records * 64u); ns.lds_nodes = (lds_cf4 *)s_nodes; ns.n_cached = P.n_cached;
+    ns.global_nodes = make_rsrc(P.nodes, (uint32_t)P.n_records * 64u);
+    ns.lds_q0 = (lds_cf4 *)s_q0; ns.lds_q1 = (lds_cf4 *)s_q1; ns.lds_q2 = (lds_cf4 *)s_q2;
+    ns.lds_r0 = (lds_cu32 *)s_r0; ns.lds_r1 = (lds_cu32 *)s_r1;
+    ns.n_cached = P.n_cached; ns.refs16 = narrow;
     const buf_rsrc tri_rsrc = make_rsrc(P.tris, P.n_tris * 48u);
     const V3 du = mk(P.du[0], P.du[1], P.du[2]), dv = mk(P.dv[0], P.dv[1], P.dv[2]);
     const V3 cam_center = mk(P.center[0], P.center[1], P.center[2]);
     const uint32_t n_local_pixels = P.tiles_local * 64u;
-    uint32_t *const my_stack = s_stack + (size_t)wave * (size_t)(P.stack_depth < 1 ? 1 : P.stack_depth) * 64u + lane;
+    StackRef my_stack;
+    {
+        const size_t depth = (size_t)(P.stack_depth < 1 ? 1 : P.stack_depth);
+        my_stack.narrow = narrow;
+        my_stack.s16 = (lds_u16 *)(s_stack_base + (size_t)wave * depth * 128u) + lane;
+        my_stack.s32 = (lds_u32 *)(s_stack_base + (size_t)wave * depth * 256u) + lane;
+    }
 
     // ---- lane state ---------------------------------------------------------------------------------------
     bool dead = false, have_path = false, result_ready = false, have_pixel = false;
@@ -121,6 +144,8 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
     Trav tv; tv.node = -1; tv.sp = 0; tv.c = kFltMax; tv.hit = -1;
     uint32_t n_rays = 0;
     TravStats ts;
+    unsigned long long t_shade = 0, t_inner = 0, t_fringe = 0, t_mark = 0;   // instrumented build: wave cycles per phase
+    if (COUNT) t_mark = __builtin_amdgcn_s_memtime();
     uint32_t cur_tile_local = 0, pixel_iters0 = 0;   // probe only
 
     for (;;) {
@@ -347,6 +372,7 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
             }
         }
 
+        if (COUNT) { const unsigned long long now = __builtin_amdgcn_s_memtime(); t_shade += now - t_mark; t_mark = now; }
         // =========================== traversal phase =========================================================
         // Two kinds of steps: INNER (record with two internal children: box tests only) and FRINGE (a leaf child:
         // box + triangle tests, several times the cost).  Lanes that reach a fringe record wait until
@@ -365,11 +391,13 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
                     trav_step_fringe<ITERS>(tv, ns, tri_rsrc, ro, rd, inv, my_stack, ts);
                     if (tv.node < 0) result_ready = true;
                 }
+                if (COUNT) { const unsigned long long now = __builtin_amdgcn_s_memtime(); t_fringe += now - t_mark; t_mark = now; }
             } else {
                 if (tv.node >= 0 && tv.node < P.n_inner) {
                     trav_step_inner<ITERS>(tv, ns, ro, inv, my_stack, ts);
                     if (tv.node < 0) result_ready = true;
                 }
+                if (COUNT) { const unsigned long long now = __builtin_amdgcn_s_memtime(); t_inner += now - t_mark; t_mark = now; }
             }
         }
     }
@@ -392,6 +420,9 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
                 atomicAdd(&P.counters[7], (unsigned long long)ts.w_fringe);
                 atomicAdd(&P.counters[8], (unsigned long long)ts.l_fringe);
                 atomicAdd(&P.counters[9], (unsigned long long)ts.l_inner);
+                atomicAdd(&P.counters[10], t_shade);
+                atomicAdd(&P.counters[11], t_inner);
+                atomicAdd(&P.counters[12], t_fringe);
             }
         }
     }
@@ -446,10 +477,12 @@ __global__ __launch_bounds__(64) void trace_rays_kernel(const RenderParams P, co
     const V3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     if (active) trav_begin<false>(tv, P.tris, P.root_ref, o, d, ts);
     NodeSrc ns;
-    ns.global_nodes = make_rsrc(P.nodes, (uint32_t)P.n_records * 64u); ns.lds_nodes = nullptr; ns.n_cached = 0;
+    ns.global_nodes = make_rsrc(P.nodes, (uint32_t)P.n_records * 64u);
+    ns.lds_q0 = ns.lds_q1 = ns.lds_q2 = nullptr; ns.lds_r0 = ns.lds_r1 = nullptr; ns.n_cached = 0; ns.refs16 = false;
     const buf_rsrc tri_rsrc = make_rsrc(P.tris, P.n_tris * 48u);
+    StackRef my_stack; my_stack.narrow = false; my_stack.s16 = nullptr; my_stack.s32 = (lds_u32 *)s_stack + lane;
     while (__ballot(tv.node >= 0) != 0ull) {
-        if (tv.node >= 0) trav_step_fringe<false>(tv, ns, tri_rsrc, o, d, inv, s_stack + lane, ts);   // handles inner records too
+        if (tv.node >= 0) trav_step_fringe<false>(tv, ns, tri_rsrc, o, d, inv, my_stack, ts);   // handles inner records too
     }
     const float t = tv.c;
     const int tri = tv.hit;
@@ -510,12 +543,12 @@ template <int MODE>
 static hipError_t launch_render_mode(const RenderParams &p_in, uint32_t n_cu, hipStream_t st) {
     RenderParams p = p_in;
     int wpb = 1, n_cached = 0;
-    render_launch_shape(p.stack_depth, p.n_records, wpb, n_cached);
+    render_launch_shape(p.stack_depth, p.n_records, p.n_inner, wpb, n_cached);
     if (p.waves_per_cu_override > 0 && p.waves_per_cu_override < 16) {   // experiment knob: smaller groups, no cache sharing
         wpb = 1; n_cached = 0;
     }
     p.n_cached = n_cached;
-    const size_t lds = render_lds_bytes(p.stack_depth, wpb, n_cached);
+    const size_t lds = render_lds_bytes(p.stack_depth, wpb, n_cached, p.n_records);
     static bool attr_set[3] = {false, false, false};
     if (!attr_set[MODE]) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget);

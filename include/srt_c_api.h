@@ -84,8 +84,8 @@ typedef struct {
      * the whole tree for them and finds nothing), [3] fringe steps, [4] lanes served by them, [5] lanes served by
      * inner steps.  SIMD utilisation of traversal =
      * node_visits / (64 * util[0]).  node_visits / tri_tests / box_tests count the work actually done. */
-    uint64_t util[7];
-    uint64_t reserved[4];
+    uint64_t util[9];   /* [6..8]: wave cycles spent in the shading phase / inner steps / fringe steps */
+    uint64_t reserved[2];
 } srt_stats;
 
 typedef struct srt_scene srt_scene;   /* host-side flattened scene (replaces scene_manager's device heap) */

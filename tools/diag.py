@@ -28,7 +28,8 @@ for count in (True, False):
         u = st["util"]
         res.update(rays=st["rays"], rays_per_path=st["rays"] / st["paths"], V=st["node_visits"] / st["rays"], T=st["tri_tests"] / st["rays"],
                    Bx=st["box_tests"] / st["rays"],
-                   trav_simd_util=st["node_visits"] / (64.0 * u[0]), alive_frac=u[1] / (64.0 * u[0]), trav_over_alive=st["node_visits"] / max(u[1], 1), nan_ray_frac=u[2] / st["rays"], fringe_steps_frac=u[3] / max(u[0], 1), fringe_lane_util=u[4] / (64.0 * max(u[3], 1)), inner_lane_util=u[5] / (64.0 * max(u[0] - u[3], 1)), ms_instrumented=best)
+                   trav_simd_util=st["node_visits"] / (64.0 * u[0]), alive_frac=u[1] / (64.0 * u[0]), trav_over_alive=st["node_visits"] / max(u[1], 1), nan_ray_frac=u[2] / st["rays"], fringe_steps_frac=u[3] / max(u[0], 1), fringe_lane_util=u[4] / (64.0 * max(u[3], 1)), inner_lane_util=u[5] / (64.0 * max(u[0] - u[3], 1)), cycles_shade_inner_fringe=[u[6] / max(u[6] + u[7] + u[8], 1), u[7] / max(u[6] + u[7] + u[8], 1), u[8] / max(u[6] + u[7] + u[8], 1)],
+                   cyc_per_inner_step=u[7] / max(u[0] - u[3], 1), cyc_per_fringe_step=u[8] / max(u[3], 1), ms_instrumented=best)
     else:
         res.update(ms=best, mray_s=st["rays"] / best / 1e3)
 print(json.dumps(res, indent=1))
