@@ -194,21 +194,6 @@ __device__ __forceinline__ bool tri_test(const float4 *__restrict__ tris, int tr
     return true;
 }
 
-// aabb::hit (bvh/aabb.cu:7-40) for one child box with the per-ray reciprocal hoisted
-// (inv = 1/dir is the same IEEE division the reference redoes per box).  The per-axis early-outs of
-// the reference are equivalent to the single final test because min only grows and max only shrinks;
-// NaN t0/t1 are ignored by both forms (comparisons false / fmaxf,fminf return the other operand).
-__device__ __forceinline__ bool box_test(float lox, float hix, float loy, float hiy, float loz, float hiz, V3 o, V3 inv,
-                                         float tmin, float tmax) {
-    const bool px = inv.x >= 0, py = inv.y >= 0, pz = inv.z >= 0;
-    float t0x = ((px ? lox : hix) - o.x) * inv.x, t1x = ((px ? hix : lox) - o.x) * inv.x;
-    float t0y = ((py ? loy : hiy) - o.y) * inv.y, t1y = ((py ? hiy : loy) - o.y) * inv.y;
-    float t0z = ((pz ? loz : hiz) - o.z) * inv.z, t1z = ((pz ? hiz : loz) - o.z) * inv.z;
-    float mn = fmaxf(fmaxf(fmaxf(tmin, t0x), t0y), t0z);
-    float mx = fminf(fminf(fminf(tmax, t1x), t1y), t1z);
-    return !(mx <= mn);
-}
-
 // BVH paired-child record (4 x float4 = 64 B, one per INTERNAL node of the reference's binary tree):
 //   q0 = { L.xmin, L.xmax, L.ymin, L.ymax }   q1 = { L.zmin, L.zmax, R.xmin, R.xmax }
 //   q2 = { R.ymin, R.ymax, R.zmin, R.zmax }   q3 = { bits(lref), bits(rref), 0, 0 }
@@ -338,7 +323,12 @@ __device__ __forceinline__ int stack_pop(const StackRef &st, int sp) {
     return st.narrow ? (int)st.s16[sp * 64] : (int)st.s32[sp * 64];
 }
 
-// c-independent part of both slab tests (x = left child, y = right child), packed fp32.
+// aabb::hit (bvh/aabb.cu:7-40) for both child boxes at once (x = left child, y = right child), packed fp32, with the
+// per-ray reciprocal hoisted (inv = 1/dir is the same IEEE division the reference redoes per box).  Returns the
+// c-independent part: e = max(tmin, t0x, t0y, t0z) and m = min(t1x, t1y, t1z); the box passes iff !(min(c, m) <= e).
+// The reference's per-axis early-outs are equivalent to this single final test because its running min only grows
+// and its running max only shrinks; NaN t0/t1 are ignored by both forms (comparisons false / fmaxf,fminf return the
+// other operand).
 __device__ __forceinline__ void box_pair(const f4v &q0, const f4v &q1, const f4v &q2, V3 o, V3 inv, float &e_l, float &m_l,
                                          float &e_r, float &m_r) {
     const bool px = inv.x >= 0, py = inv.y >= 0, pz = inv.z >= 0;

@@ -222,7 +222,7 @@ int build_bvh_sah(srt_scene &s) {
     s.nodes.emplace_back();
     s.root = 0;
     stack.push_back({0, n, 0});
-    constexpr int kBins = 16;
+    constexpr int kBins = 32;
     while (!stack.empty()) {
         const Span cur = stack.back();
         stack.pop_back();
