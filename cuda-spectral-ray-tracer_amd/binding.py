@@ -64,6 +64,7 @@ PROTOTYPES = {
     "srt_scene_get_tri_records": (_i, [_vp, _fp]),
     "srt_material_bake": (_i, [C.POINTER(Material)]),
     "srt_bake_sigmoid_spectrum": (_i, [_fp, _f, _i, _fp]),
+    "srt_fit_sigmoid_coeffs": (_i, [_fp, _fp]),
     "srt_background_spectrum": (_i, [_fp, _fp]),
     "srt_scene_build_bvh": (_i, [_vp, _i, _u64]),
     "srt_scene_node_count": (_sz, [_vp]),

@@ -542,21 +542,76 @@ static srt_material make_material(uint32_t type, float r, float g, float b, floa
 static const float kFlintB[3] = {1.34533359f, 0.209073176f, 0.937357162f};   // refraction/sellmeier.cuh:14
 static const float kBK7B[3] = {1.03961212f, 0.231792344f, 1.01046945f};      // refraction/sellmeier.cuh:6
 
-// Stand-in sigmoid coefficients for the three non-grey Cornell colours.  The reference gets these from the
-// pbrt rgb2spec table (utils/srgb_to_spectrum.cu), which is absent from the reference mount: these smooth
-// spectra are this build's own choice ("parity unpinned" vs the author's table).
-static void bake_or_standin(srt_material &m) {
-    if (srt_material_bake(&m) == SRT_OK) return;
-    const float r = m.col[0], g = m.col[1], b = m.col[2];
-    // peak wavelength by dominant channel, width/height from the channel values
-    const float hi = fmaxf(r, fmaxf(g, b)), lo = fminf(r, fminf(g, b));
-    const float peak = (r >= g && r >= b) ? 640.f : ((g >= b) ? 540.f : 455.f);
-    // sigmoid(c2 (l-peak)^2 + c0): c0 from the high value, c2 so that 120 nm away it falls to the low value
-    auto inv_sig = [](float y) { y = fminf(fmaxf(y, 0.01f), 0.99f); float t = 2.f * y - 1.f; return t / sqrtf(1.f - t * t); };
-    const float a0 = inv_sig(hi), a1 = inv_sig(lo);
-    const float c2 = (a1 - a0) / (120.f * 120.f);
-    const float coeffs[3] = {c2 * peak * peak + a0, -2.f * c2 * peak, c2};
-    srt_bake_sigmoid_spectrum(coeffs, 1.0f, 0, m.spectral_distribution);
+// sRGB -> sigmoid-polynomial spectrum for NON-grey colours.  The reference reads these coefficients from the pbrt-v4
+// rgb2spec table (utils/srgb_to_spectrum.cu: Jakob & Hanika 2019, "A Low-Dimensional Function Space for Efficient
+// Spectral Upsampling"), which is absent from the reference mount.  This is the build's own fit of the same model
+// (SURVEY 8(f) row f4): find (c0, c1, c2) such that s(l) = sigmoid(c2 x^2 + c1 x + c0), x = (l-360)/470, seen under D65
+// through the CIE 1931 observer and the XYZ->sRGB matrix reproduces the colour's linear sRGB; Gauss-Newton with a
+// numerical Jacobian on the 95-sample tables.  "Parity unpinned" against the author's table (which also differs from
+// a fit through quirk Q3), the baked 95-sample spectrum is a scene input, so checker and GPU consume identical data.
+static void model_rgb(const double c[3], double out[3]) {
+    cie_init();
+    double X = 0, Y = 0, Z = 0, Yw = 0;
+    for (int k = 0; k < SRT_N_CIE_SAMPLES; k++) {
+        const double x = (double)k / (SRT_N_CIE_SAMPLES - 1);
+        const double p = (c[2] * x + c[1]) * x + c[0];
+        const double sg = 0.5 * p / sqrt(1.0 + p * p) + 0.5;
+        const double w = g_cie[3][k];
+        X += g_cie[0][k] * w * sg; Y += g_cie[1][k] * w * sg; Z += g_cie[2][k] * w * sg; Yw += g_cie[1][k] * w;
+    }
+    X /= Yw; Y /= Yw; Z /= Yw;
+    out[0] = 3.2404542 * X - 1.5371385 * Y - 0.4985314 * Z;
+    out[1] = -0.9692660 * X + 1.8760108 * Y + 0.0415560 * Z;
+    out[2] = 0.0556434 * X - 0.2040259 * Y + 1.0572252 * Z;
+}
+static double srgb_to_linear(double v) { return v < 0.04045 ? v / 12.92 : pow((v + 0.055) / 1.055, 2.4); }   // color.cu:8-13
+
+// returns coefficients for the reference's evaluator: polynomial(lambda, c[2], c[1], c[0]) in RAW wavelength (nm)
+static void fit_sigmoid_coeffs(const float rgb[3], float out[3]) {
+    const double target[3] = {srgb_to_linear(rgb[0]), srgb_to_linear(rgb[1]), srgb_to_linear(rgb[2])};
+    double c[3] = {0, 0, 0};
+    for (int it = 0; it < 60; it++) {
+        double r0[3];
+        model_rgb(c, r0);
+        double res[3] = {r0[0] - target[0], r0[1] - target[1], r0[2] - target[2]};
+        if (fabs(res[0]) + fabs(res[1]) + fabs(res[2]) < 1e-9) break;
+        double J[3][3];
+        for (int j = 0; j < 3; j++) {
+            double cp[3] = {c[0], c[1], c[2]}, rp[3];
+            cp[j] += 1e-5;
+            model_rgb(cp, rp);
+            for (int i = 0; i < 3; i++) J[i][j] = (rp[i] - r0[i]) / 1e-5;
+        }
+        // solve J * d = -res (3x3, Cramer) with a little damping for the near-saturated colours
+        for (int i = 0; i < 3; i++) J[i][i] += 1e-9;
+        const double det = J[0][0] * (J[1][1] * J[2][2] - J[1][2] * J[2][1]) - J[0][1] * (J[1][0] * J[2][2] - J[1][2] * J[2][0]) +
+                           J[0][2] * (J[1][0] * J[2][1] - J[1][1] * J[2][0]);
+        if (fabs(det) < 1e-30) break;
+        double d[3];
+        for (int j = 0; j < 3; j++) {
+            double M[3][3];
+            for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) M[a][b] = (b == j) ? -res[a] : J[a][b];
+            d[j] = (M[0][0] * (M[1][1] * M[2][2] - M[1][2] * M[2][1]) - M[0][1] * (M[1][0] * M[2][2] - M[1][2] * M[2][0]) +
+                    M[0][2] * (M[1][0] * M[2][1] - M[1][1] * M[2][0])) / det;
+        }
+        double step = 1.0;
+        const double norm = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+        if (norm > 20.0) step = 20.0 / norm;          // trust region
+        for (int j = 0; j < 3; j++) c[j] += step * d[j];
+    }
+    // x = (l - 360)/470  ->  raw-wavelength polynomial
+    const double a = 1.0 / 470.0, b = -360.0 / 470.0;
+    out[2] = (float)(c[2] * a * a);
+    out[1] = (float)(2.0 * c[2] * a * b + c[1] * a);
+    out[0] = (float)(c[2] * b * b + c[1] * b + c[0]);
+}
+
+static void bake_or_fit(srt_material &m) {
+    if (srt_material_bake(&m) == SRT_OK) return;      // grey / white / light / glass: the reference's closed forms
+    float coeffs[3];
+    fit_sigmoid_coeffs(m.col, coeffs);
+    if (m.material_type == SRT_MAT_EMISSIVE) bake_sigmoid(coeffs, srt_powf(m.emission_power, 2.0f), true, m.spectral_distribution);
+    else bake_sigmoid(coeffs, 1.0f, false, m.spectral_distribution);
 }
 
 static void cornell_walls_and_light(Builder &B, const uint32_t wall_mats[5], uint32_t light_mat) {
@@ -605,7 +660,7 @@ static void scene_cornell(srt_scene &s, bool different_mats) {
         s.mats.push_back(make_material(SRT_MAT_DIELECTRIC, 1.f, 1.f, 1.f, 1.f, 0.f, kBK7B));
         s.mats.push_back(make_material(SRT_MAT_METALLIC, .7f, .7f, .7f, 0.8f, 0.f));
     }
-    for (auto &m : s.mats) bake_or_standin(m);
+    for (auto &m : s.mats) bake_or_fit(m);
     Builder B(s);
     // wall order in d_list: bottom, top, back, left, right (scene.cu:83-95)
     const uint32_t walls_c[5] = {3, 3, 3, 1, 6}, walls_t[5] = {6, 2, 1, 8, 5};
@@ -626,7 +681,7 @@ static void scene_prism(srt_scene &s) {
     s.mats.push_back(make_material(SRT_MAT_LAMBERTIAN, (float).73, (float).73, (float).73, 1.f, 0.f));
     s.mats.push_back(make_material(SRT_MAT_EMISSIVE, 1.f, 1.f, 1.f, 1.f, 5.f));
     s.mats.push_back(make_material(SRT_MAT_DIELECTRIC, 1.f, 1.f, 1.f, 1.f, 0.f, kFlintB));
-    for (auto &m : s.mats) bake_or_standin(m);
+    for (auto &m : s.mats) bake_or_fit(m);
     Builder B(s);
     const uint32_t walls[5] = {0, 0, 0, 0, 0};
     cornell_walls_and_light(B, walls, 1);
@@ -740,7 +795,7 @@ static void scene_random_spheres(srt_scene &s, uint64_t seed) {
     Builder B(s);
     {   // ground: grey 0.5 -> spectrum 0.5 everywhere (Q2 keeps 0.5 at 0.5)
         srt_material g = make_material(SRT_MAT_LAMBERTIAN, 0.5f, 0.5f, 0.5f, 1.f, 0.f);
-        bake_or_standin(g);
+        bake_or_fit(g);
         s.mats.push_back(g);
         B.quad(f3(-1000.f, 0.f, -1000.f), f3(0.f, 0.f, 2000.f), f3(2000.f, 0.f, 0.f), 0);
     }
@@ -762,9 +817,14 @@ static void scene_random_spheres(srt_scene &s, uint64_t seed) {
         s.mats.push_back(synthetic_material(rng, SRT_MAT_LAMBERTIAN, 1.f)); add_icosphere(B, f3(-4.f, 1.f, 0.f), 1.0f, 2, (uint32_t)s.mats.size() - 1);
         s.mats.push_back(synthetic_material(rng, SRT_MAT_METALLIC, 0.0f)); add_icosphere(B, f3(4.f, 1.f, 0.f), 1.0f, 2, (uint32_t)s.mats.size() - 1);
     }
-    // sky: bluish sigmoid times normalised D65 (stand-in for background (0.7,0.8,1.0), which needs the missing table)
-    const float sky[3] = {3.0f, -0.004f, 0.f};   // sigmoid(3 - 0.004 l): 0.93 at 400 nm -> 0.42 at 800 nm
-    srt_bake_sigmoid_spectrum(sky, 1.0f, 1, s.background);
+    // sky: background colour (0.70, 0.80, 1.00) -- RTIOW's, and the one commented out in scene.cu:268 -- as an illuminance
+    // spectrum: fitted sigmoid times normalised D65, power 1 (srgb_to_illuminance_spectrum, color_to_spectrum.cuh:158-171)
+    {
+        const float sky_rgb[3] = {0.70f, 0.80f, 1.00f};
+        float sky[3];
+        fit_sigmoid_coeffs(sky_rgb, sky);
+        bake_sigmoid(sky, srt_powf(1.0f, 2.0f), true, s.background);
+    }
     s.cam.vfov = 20.f;
     s.cam.lookfrom[0] = 13.f; s.cam.lookfrom[1] = 2.f; s.cam.lookfrom[2] = 3.f;
     s.cam.lookat[0] = s.cam.lookat[1] = s.cam.lookat[2] = 0.f;
@@ -779,7 +839,7 @@ static void scene_mesh100k(srt_scene &s, uint64_t seed) {
     s.mats.push_back(make_material(SRT_MAT_LAMBERTIAN, .73f, .73f, .73f, 1.f, 0.f));
     s.mats.push_back(make_material(SRT_MAT_EMISSIVE, 1.f, 1.f, 1.f, 1.f, 5.f));
     s.mats.push_back(make_material(SRT_MAT_DIELECTRIC, 1.f, 1.f, 1.f, 1.f, 0.f, kFlintB));
-    for (auto &m : s.mats) bake_or_standin(m);
+    for (auto &m : s.mats) bake_or_fit(m);
     s.mats.push_back(synthetic_material(rng, SRT_MAT_LAMBERTIAN, 1.f));
     s.mats.push_back(synthetic_material(rng, SRT_MAT_METALLIC, 0.2f));
     Builder B(s);
@@ -947,6 +1007,11 @@ int srt_material_bake(srt_material *m) {
         bake_sigmoid(c, 1.0f, false, m->spectral_distribution);
         return SRT_OK;
     }
+}
+int srt_fit_sigmoid_coeffs(const float rgb[3], float coeffs[3]) {
+    if (!rgb || !coeffs) { set_global_error("fit: bad argument"); return SRT_ERR_INVALID; }
+    fit_sigmoid_coeffs(rgb, coeffs);
+    return SRT_OK;
 }
 int srt_background_spectrum(const float rgb[3], float *out) {
     float c[3];

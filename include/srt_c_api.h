@@ -127,6 +127,10 @@ SRT_API int srt_material_bake(srt_material *m);
 /* dev_srgb_to_spectrum / dev_srgb_to_illuminance_spectrum evaluated from explicit sigmoid coefficients
  * (color/color_to_spectrum.cuh:173-186,204-219): value = [scale * D65n(l)] * sigmoid(c[2] l^2 + c[1] l + c[0]). */
 SRT_API int srt_bake_sigmoid_spectrum(const float coeffs[3], float scale, int times_d65, float out[SRT_N_CIE_SAMPLES]);
+/* Own Jakob-Hanika style fit of the sigmoid coefficients of a NON-grey sRGB colour (replaces the lookup in the pbrt
+ * rgb2spec table of color/color_to_spectrum.cuh:109-151, which the reference mount lacks).  coeffs are in the layout
+ * srt_bake_sigmoid_spectrum expects.  Not pinned against the author's table. */
+SRT_API int srt_fit_sigmoid_coeffs(const float rgb[3], float coeffs[3]);
 /* host srgb_to_illuminance_spectrum for the background (rendering/rendering.cu:324), grey colours only. */
 SRT_API int srt_background_spectrum(const float rgb[3], float out[SRT_N_CIE_SAMPLES]);
 

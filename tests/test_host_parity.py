@@ -126,3 +126,28 @@ def test_error_paths(srt):
     m = (srt.Material * 1)()
     s1 = srt.Scene.from_arrays(t, m, np.zeros(95, np.float32)).build_bvh(srt.BVH_REFERENCE)
     assert s1.n_nodes == 1 and s1.bvh()[2][0] == 0
+
+
+def test_sigmoid_fit_round_trip(srt, orc):
+    """Own Jakob-Hanika fit (the reference's rgb2spec table is absent upstream): the fitted reflectance, seen under D65
+    through the CIE observer and the reference's XYZ->sRGB, reproduces the requested colour."""
+    L = srt.binding.lib()
+    cie = np.array([[orc.lib().orc_cie_table(w, k) for k in range(95)] for w in range(4)], np.float64)
+    for rgb in ((.65, .05, .05), (.12, .45, .15), (.12, .15, .45), (.7, .8, 1.0), (.9, .9, .1)):
+        c = np.zeros(3, np.float32)
+        assert L.srt_fit_sigmoid_coeffs(srt.binding.fptr(np.array(rgb, np.float32)), srt.binding.fptr(c)) == 0
+        lam = 360.0 + 5.0 * np.arange(95)
+        p = c[2] * lam * lam + c[1] * lam + c[0]
+        sd = 0.5 * p / np.sqrt(1 + p * p) + 0.5
+        w = cie[3]
+        X, Y, Z = [(cie[i] * w * sd).sum() / (cie[1] * w).sum() for i in range(3)]
+        lin = np.array([3.2404542 * X - 1.5371385 * Y - 0.4985314 * Z, -0.9692660 * X + 1.8760108 * Y + 0.0415560 * Z,
+                        0.0556434 * X - 0.2040259 * Y + 1.0572252 * Z])
+        enc = np.where(lin < 0.0031308, 12.92 * lin, 1.055 * np.clip(lin, 0, None) ** (1 / 2.4) - 0.055)
+        assert np.max(np.abs(enc - np.array(rgb))) < 5e-3, (rgb, enc)
+    # the Cornell walls use it: red / green / blue spectra are smooth, in [0, 1] and distinct
+    mats = srt.Scene.builtin(srt.SCENE_CORNELL).materials()
+    red, green, blue = (np.array(mats[k].spectral_distribution) for k in (0, 1, 6))
+    for sdv in (red, green, blue):
+        assert sdv.min() >= 0 and sdv.max() <= 1 and np.abs(np.diff(sdv)).max() < 0.1
+    assert red[60] > 5 * red[20] and blue[20] > 3 * blue[70] and green[38] > 3 * green[80]
