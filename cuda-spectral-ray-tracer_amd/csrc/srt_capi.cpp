@@ -250,13 +250,7 @@ int srt_render_chunk(srt_ctx *c, uint32_t width, uint32_t height, uint32_t offx,
         RenderParams pp = p;
         pp.spp = c->probe_spp; pp.tile_cost = c->d_tile_cost;
         HIP_TRY(c, launch_render(pp, (uint32_t)c->n_cu, 2, st));
-        std::vector<uint32_t> cost(c->tiles_local), order(c->tiles_local);
-        HIP_TRY(c, hipMemcpyAsync(cost.data(), c->d_tile_cost, c->tiles_local * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        HIP_TRY(c, hipStreamSynchronize(st));
-        for (uint32_t k = 0; k < c->tiles_local; k++) order[k] = k;
-        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
-        HIP_TRY(c, hipMemcpyAsync(c->d_tile_order, order.data(), c->tiles_local * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-        HIP_TRY(c, hipStreamSynchronize(st));     // `order` is a stack vector
+        HIP_TRY(c, launch_order_tiles(c->d_tile_cost, c->d_tile_order, c->tiles_local, st));      // device-side, no host sync
         HIP_TRY(c, hipMemsetAsync(c->d_counters + kCounters, 0, sizeof(unsigned long long), st));   // rewind the queue head
         p.tile_order = c->d_tile_order;
     }

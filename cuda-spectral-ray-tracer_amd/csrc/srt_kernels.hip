@@ -428,6 +428,33 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
     }
 }
 
+// Cost-descending order of the local tiles for the pixel queue (longest-processing-time-first), on the device so that
+// srt_render_chunk never has to synchronise with the host: one workgroup, 4096-bin counting sort on the probe's per-tile
+// cost.  The order inside a bin is arbitrary -- it only affects scheduling, never results.
+__global__ __launch_bounds__(1024) void order_tiles_kernel(const uint32_t *__restrict__ cost, uint32_t *__restrict__ order, uint32_t n) {
+    constexpr uint32_t kBinsN = 4096;
+    __shared__ uint32_t s_bin[kBinsN];
+    __shared__ uint32_t s_max;
+    const uint32_t t = threadIdx.x;
+    if (t == 0) s_max = 1u;
+    for (uint32_t b = t; b < kBinsN; b += 1024) s_bin[b] = 0u;
+    __syncthreads();
+    uint32_t m = 0;
+    for (uint32_t k = t; k < n; k += 1024) m = max(m, cost[k]);
+    atomicMax(&s_max, m);
+    __syncthreads();
+    const float scale = (float)(kBinsN - 1) / (float)s_max;
+    auto bin_of = [&](uint32_t c) { uint32_t b = (uint32_t)((float)c * scale); b = b > kBinsN - 1 ? kBinsN - 1 : b; return (kBinsN - 1) - b; };   // bin 0 = most expensive
+    for (uint32_t k = t; k < n; k += 1024) atomicAdd(&s_bin[bin_of(cost[k])], 1u);
+    __syncthreads();
+    if (t == 0) {       // exclusive scan of 4096 counters: trivial next to a multi-second render
+        uint32_t acc = 0;
+        for (uint32_t b = 0; b < kBinsN; b++) { const uint32_t c = s_bin[b]; s_bin[b] = acc; acc += c; }
+    }
+    __syncthreads();
+    for (uint32_t k = t; k < n; k += 1024) order[atomicAdd(&s_bin[bin_of(cost[k])], 1u)] = k;
+}
+
 // Gathered compact tiles -> block-linear planar framebuffer (rendering.cu:146-148 layout).
 __global__ __launch_bounds__(64) void scatter_tiles_kernel(const ScatterParams P) {
     const uint32_t tile = blockIdx.x;
@@ -568,6 +595,12 @@ hipError_t launch_render(const RenderParams &p, uint32_t n_cu, int mode, hipStre
     if (mode == 1) return launch_render_mode<1>(p, n_cu, st);
     if (mode == 2) return launch_render_mode<2>(p, n_cu, st);
     return launch_render_mode<0>(p, n_cu, st);
+}
+
+hipError_t launch_order_tiles(const uint32_t *cost, uint32_t *order, uint32_t n, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(order_tiles_kernel, dim3(1), dim3(1024), 0, st, cost, order, n);
+    return hipGetLastError();
 }
 
 hipError_t launch_scatter(const ScatterParams &p, hipStream_t st) {

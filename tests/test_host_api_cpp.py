@@ -25,11 +25,11 @@ def test_cpp_mirror_compiles_and_links(srt):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("chunk", [(0, 0), (40, 40)])
-def test_render_manager_matches_oracle(srt, orc, tmp_path, chunk):
+@pytest.mark.parametrize("chunk,spp", [((0, 0), 6), ((40, 40), 6), ((40, 40), 12)])   # 12 spp: the cost probe + ordered queue run per chunk
+def test_render_manager_matches_oracle(srt, orc, tmp_path, chunk, spp):
     if not os.path.exists(EXE):
         build_demo()
-    W, H, spp, depth = 72, 56, 6, 8
+    W, H, depth = 72, 56, 8
     out = str(tmp_path / "img.bin")
     subprocess.check_call([EXE, "1", str(W), str(H), str(spp), str(depth), str(chunk[0]), str(chunk[1]), out], timeout=120)
     got = np.fromfile(out, np.float32).reshape(3, H, W)
