@@ -70,6 +70,8 @@ def main():
     ap.add_argument("--depth", type=int, default=16)
     ap.add_argument("--bvh", type=int, default=1)              # SRT_BVH_SAH for the synthetic scenes
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse-gloo", action="store_true",
+                    help="rehearsal of the N>1 path on ONE GPU: all ranks use cuda:0 and the gather goes through gloo/host (never used for reported numbers)")
     ap.add_argument("--pmc-traffic-bytes", type=float, default=None,
                     help="HBM bytes per launch from a separate rocprofv3 --pmc pass; default: profiles/r01/hbm_traffic.json when the workload matches")
     args = ap.parse_args()
@@ -86,10 +88,15 @@ def main():
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
+    if args.rehearse_gloo:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.rehearse_gloo:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     import __graft_entry__
     srt = __graft_entry__._pkg()
@@ -111,7 +118,8 @@ def main():
     r.set_count_traversal(True)
     r.render_chunk(W, H, 0, 0, stream)
     st = r.stats()
-    cnt = torch.tensor([st["rays"], st["node_visits"], st["tri_tests"], st["paths"]], dtype=torch.float64, device="cuda")
+    red_dev = "cpu" if args.rehearse_gloo else "cuda"
+    cnt = torch.tensor([st["rays"], st["node_visits"], st["tri_tests"], st["paths"]], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(cnt)
     rays_c, V_c, T_c, paths_c = [float(x) for x in cnt.tolist()]
@@ -122,22 +130,26 @@ def main():
     r.init_device_params(W, H, args.spp, args.depth, 1984)
     geom = dict(r.geom)
 
-    def gathered_view():
-        ptr, n_floats, tl, tp = r.tile_buffer()
-
-        class _Wrap:
-            __cuda_array_interface__ = {"shape": (tp, tiles.PLANES, tiles.LANES), "typestr": "<f4", "data": (ptr, False), "version": 2}
-        return torch.as_tensor(_Wrap(), device="cuda")
+    local_tiles = None      # torch-owned staging tensor for the gather (multi-rank only)
 
     def step():
+        nonlocal local_tiles
         r.render_chunk(W, H, 0, 0, stream)
         if world == 1:
             r.scatter_tiles(None, stream)
         else:
-            local = gathered_view()
-            g = tiles.gather_tiles(local, rank, world)            # the single collective of the path
+            if local_tiles is None:
+                _, _, _, tp = r.tile_buffer()
+                local_tiles = torch.empty((tp, tiles.PLANES, tiles.LANES), dtype=torch.float32, device="cuda")
+            r.copy_tile_buffer(local_tiles.data_ptr(), stream)        # stream-ordered D2D into the tensor RCCL sends
+            if args.rehearse_gloo:
+                gh = tiles.gather_tiles(local_tiles.cpu(), rank, world)
+                g = gh.cuda() if rank == 0 else None
+            else:
+                g = tiles.gather_tiles(local_tiles, rank, world)      # the single collective of the path (RCCL over xGMI)
             if rank == 0:
                 r.scatter_tiles(g.data_ptr(), stream)
+                torch.cuda.current_stream().synchronize() if args.rehearse_gloo else None
         return r
 
     def barrier():
@@ -167,7 +179,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
 
-    tot = torch.tensor([float(rays_local), elapsed, sum(kernel_ms) / max(len(kernel_ms), 1)], dtype=torch.float64, device="cuda")
+    tot = torch.tensor([float(rays_local), elapsed, sum(kernel_ms) / max(len(kernel_ms), 1)], dtype=torch.float64, device=red_dev)
     if world > 1:
         rays_t = tot[0:1].clone(); dist.all_reduce(rays_t)
         mx = tot[1:3].clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
@@ -186,6 +198,8 @@ def main():
         mray = total_rays / elapsed / 1e6
         rays_per_launch_rank0 = rays_local / steps
         achieved = rays_per_launch_rank0 * b_ray / (kms * 1e-3) / 1e9            # GB/s, dominant kernel on this rank
+        fb = r.read_fb()                       # outside the timed region: image checksum, identical for every N
+        checksum = int(sum(int(p.astype("int64").sum()) for p in fb))
         out = {
             "metric": "Mray/s", "value": mray, "unit": "Mray/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
@@ -195,7 +209,7 @@ def main():
                        "scene_id": args.scene, "tiles": "8x8 px per wave, rank = tile % n_gpus", "gather": "1 RCCL gather of compact tiles"},
             "mpath_per_s": (W * H * args.spp * steps) / elapsed / 1e6,
             "rays_per_path": rays_per_path, "node_records_per_ray_V": V, "tri_tests_per_ray_T": T, "algorithmic_bytes_per_ray": b_ray,
-            "kernel_ms_per_step": kms,
+            "kernel_ms_per_step": kms, "fb_checksum": checksum,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic,
                          "note": "achieved = algorithmic bytes (V*64 + T*48 + 56 per ray) / render-kernel time. The scene is "

@@ -80,6 +80,7 @@ PROTOTYPES = {
     "srt_render_chunk": (_i, [_vp, _u32, _u32, _u32, _u32, _vp]),
     "srt_synchronize": (_i, [_vp]),
     "srt_tile_buffer": (_i, [_vp, C.POINTER(_vp), C.POINTER(_sz), C.POINTER(_u32), C.POINTER(_u32)]),
+    "srt_copy_tile_buffer": (_i, [_vp, _vp, _vp]),
     "srt_scatter_tiles": (_i, [_vp, _vp, _vp]),
     "srt_dev_fb": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_sz)]),
     "srt_read_fb": (_i, [_vp, _fp, _fp, _fp]),

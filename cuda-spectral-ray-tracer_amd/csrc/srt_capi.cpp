@@ -278,6 +278,13 @@ int srt_tile_buffer(srt_ctx *c, void **dev_ptr, size_t *n_floats, uint32_t *tile
     return SRT_OK;
 }
 
+int srt_copy_tile_buffer(srt_ctx *c, void *dst_dev, void *stream) {
+    if (!c || !c->d_tiles || !dst_dev) return fail(c, SRT_ERR_INVALID, "srt_copy_tile_buffer: nothing rendered yet / null destination");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpyAsync(dst_dev, c->d_tiles, (size_t)c->tiles_padded * kTilePlanes * kTileLanes * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return SRT_OK;
+}
+
 int srt_scatter_tiles(srt_ctx *c, const void *dev_gathered, void *stream) {
     if (!c || !c->d_fb || !c->d_tiles) return fail(c, SRT_ERR_INVALID, "srt_scatter_tiles: nothing rendered yet");
     if (!dev_gathered) {

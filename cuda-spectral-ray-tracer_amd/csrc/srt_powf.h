@@ -23,6 +23,13 @@ SRT_HD float srt_powf(float xf, float yf) {
     if (xf < 0.0f) return __builtin_nanf("");
     if (__builtin_isinf(xf)) return yf > 0.0f ? __builtin_inff() : 0.0f;
     double x = (double)xf, y = (double)yf;
+    if (yf == 5.0f) {
+        /* Schlick's (1-cos)^5 (materials/material.cu:48), the only integer exponent on the per-ray path: x^2 is exact in
+         * fp64 (48 bits), the two further products round once each, so the result is within 2.2e-16 of x^5 before the
+         * single rounding to fp32 -- the same accuracy class as the general branch at a fraction of the cost. */
+        const double x2 = x * x;
+        return (float)((x2 * x2) * x);
+    }
     uint64_t bits;
     __builtin_memcpy(&bits, &x, 8);
     int e = (int)((bits >> 52) & 0x7ffu) - 1023;

@@ -66,6 +66,9 @@ class Renderer:
         self._ck(B.lib().srt_tile_buffer(self._h, C.byref(ptr), C.byref(n), C.byref(tl), C.byref(tp)))
         return ptr.value, n.value, tl.value, tp.value
 
+    def copy_tile_buffer(self, dst_ptr, stream=None):
+        self._ck(B.lib().srt_copy_tile_buffer(self._h, C.c_void_p(dst_ptr), C.c_void_p(stream or 0)))
+
     def scatter_tiles(self, gathered_ptr=None, stream=None):
         self._ck(B.lib().srt_scatter_tiles(self._h, C.c_void_p(gathered_ptr or 0), C.c_void_p(stream or 0)))
 

@@ -178,6 +178,9 @@ SRT_API int srt_synchronize(srt_ctx *ctx);
  * [tile][plane][lane], planes = quantised r,g,b | unquantised sRGB r,g,b | XYZ sums.  tiles_padded is the
  * per-rank tile capacity ceil(n_tiles/world) so that every rank's buffer has the same size. */
 SRT_API int srt_tile_buffer(srt_ctx *ctx, void **dev_ptr, size_t *n_floats, uint32_t *tiles_local, uint32_t *tiles_padded);
+/* Stream-ordered device-to-device copy of the tile buffer into caller-owned device memory (e.g. the tensor that is
+ * handed to the RCCL gather): n_floats as reported by srt_tile_buffer. */
+SRT_API int srt_copy_tile_buffer(srt_ctx *ctx, void *dst_dev, void *stream);
 /* Scatter gathered tile buffers (device pointer, world * tiles_padded * 9 * 64 floats, rank-major) into this
  * context's block-linear planar framebuffer (rendering.cu:146-148 layout).  With world == 1 pass the
  * context's own tile buffer (or NULL to use it). */

@@ -153,10 +153,10 @@ def test_partition_invariance_and_chunks(srt, gpu, orc):
             gpu.render_chunk(W, H)
             gpu.synchronize()
             ptr, n_floats, tl, tp = gpu.tile_buffer()
-
-            class _Wrap:      # zero-copy view of the library's device buffer (same trick bench.py uses for the gather)
-                __cuda_array_interface__ = {"shape": (n_floats,), "typestr": "<f4", "data": (ptr, False), "version": 2}
-            parts.append(torch.as_tensor(_Wrap(), device="cuda").cpu().numpy().copy())
+            staging = torch.empty(n_floats, dtype=torch.float32, device="cuda")      # what bench.py hands to the RCCL gather
+            gpu.copy_tile_buffer(staging.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            parts.append(staging.cpu().numpy().copy())
         gathered = torch.from_numpy(np.concatenate(parts)).cuda()
         gpu.scatter_tiles(gathered.data_ptr())
         gpu.synchronize()
