@@ -86,6 +86,7 @@ PROTOTYPES = {
     "srt_read_fb": (_i, [_vp, _fp, _fp, _fp]),
     "srt_read_fb_rowmajor": (_i, [_vp, _fp, _fp, _fp, _u32, _u32]),
     "srt_read_fb_aux": (_i, [_vp, _i, _fp, _fp, _fp]),
+    "srt_get_tile_costs": (_i, [_vp, C.POINTER(C.c_uint32), _sz]),
     "srt_get_stats": (_i, [_vp, C.POINTER(Stats)]),
     "srt_set_count_traversal": (_i, [_vp, _i]),
     "srt_last_kernel_ms": (_i, [_vp, C.POINTER(_f)]),

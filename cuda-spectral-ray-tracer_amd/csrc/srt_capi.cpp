@@ -40,6 +40,7 @@ struct srt_ctx {
     int n_cu = 256;
     uint32_t fringe_threshold = 20;                    // env SRT_FRINGE_THRESHOLD
     uint32_t shade_threshold = 32, waves_per_cu = 0;   // tuning knobs (env SRT_SHADE_THRESHOLD / SRT_WAVES_PER_CU)
+    bool latency_mode = true;                          // env SRT_LATENCY_MODE=0 disables priorities / threshold scaling
     uint32_t probe_spp = 2;                            // samples of the cost probe (env SRT_PROBE_SPP, 0 = no ordering)
     uint32_t *d_tile_cost = nullptr, *d_tile_order = nullptr;
     size_t tile_sched_capacity = 0;
@@ -114,6 +115,7 @@ int srt_create(int device, srt_ctx **out) {
     if (const char *ev = getenv("SRT_SHADE_THRESHOLD")) c->shade_threshold = (uint32_t)std::max(1, atoi(ev));
     if (const char *ev = getenv("SRT_WAVES_PER_CU")) c->waves_per_cu = (uint32_t)std::max(0, atoi(ev));
     if (const char *ev = getenv("SRT_PROBE_SPP")) c->probe_spp = (uint32_t)std::max(0, atoi(ev));
+    if (const char *ev = getenv("SRT_LATENCY_MODE")) c->latency_mode = atoi(ev) != 0;
     if (const char *ev = getenv("SRT_FRINGE_THRESHOLD")) c->fringe_threshold = (uint32_t)std::max(1, atoi(ev));
     {
         hipDeviceProp_t prop;
@@ -236,23 +238,24 @@ int srt_render_chunk(srt_ctx *c, uint32_t width, uint32_t height, uint32_t offx,
     // A pixel is one sequential RNG stream, so the launch cannot finish before its most expensive pixel does.  A short
     // probe (probe_spp samples per pixel from a copy of the RNG state, nothing written) measures the traversal cost of
     // every tile; the queue then hands tiles out in descending cost order (longest-processing-time-first).
-    p.tile_order = nullptr; p.tile_cost = nullptr;
+    p.tile_order = nullptr; p.tile_cost = nullptr; p.sched = nullptr;
     const bool ordered = c->probe_spp > 0 && c->spp > 4 * c->probe_spp && c->tiles_local > 1;
     if (ordered) {
         if (c->tiles_local > c->tile_sched_capacity) {
             if (c->d_tile_cost) { (void)hipFree(c->d_tile_cost); c->d_tile_cost = nullptr; }
             if (c->d_tile_order) { (void)hipFree(c->d_tile_order); c->d_tile_order = nullptr; }
             HIP_TRY(c, hipMalloc((void **)&c->d_tile_cost, c->tiles_local * sizeof(uint32_t)));
-            HIP_TRY(c, hipMalloc((void **)&c->d_tile_order, c->tiles_local * sizeof(uint32_t)));
+            HIP_TRY(c, hipMalloc((void **)&c->d_tile_order, (c->tiles_local + 4) * sizeof(uint32_t)));   // + 3 class boundaries
             c->tile_sched_capacity = c->tiles_local;
         }
         HIP_TRY(c, hipMemsetAsync(c->d_tile_cost, 0, c->tiles_local * sizeof(uint32_t), st));
         RenderParams pp = p;
         pp.spp = c->probe_spp; pp.tile_cost = c->d_tile_cost;
         HIP_TRY(c, launch_render(pp, (uint32_t)c->n_cu, 2, st));
-        HIP_TRY(c, launch_order_tiles(c->d_tile_cost, c->d_tile_order, c->tiles_local, st));      // device-side, no host sync
+        HIP_TRY(c, launch_order_tiles(c->d_tile_cost, c->d_tile_order, c->tiles_local, c->d_tile_order + c->tiles_local, st));   // device-side, no host sync
         HIP_TRY(c, hipMemsetAsync(c->d_counters + kCounters, 0, sizeof(unsigned long long), st));   // rewind the queue head
         p.tile_order = c->d_tile_order;
+        if (c->latency_mode) p.sched = c->d_tile_order + c->tiles_local;
     }
     HIP_TRY(c, hipEventRecord(c->ev0, st));     // ev0..ev1 bracket the render kernel alone (roofline.achieved)
     HIP_TRY(c, launch_render(p, (uint32_t)c->n_cu, c->count_traversal ? 1 : 0, st));
@@ -352,6 +355,14 @@ int srt_read_fb_rowmajor(srt_ctx *c, float *r, float *g, float *b, uint32_t imag
     return SRT_OK;
 }
 
+int srt_get_tile_costs(srt_ctx *c, uint32_t *out, size_t n) {
+    if (!c || !out || !c->d_tile_cost || n > c->tile_sched_capacity) return fail(c, SRT_ERR_INVALID, "srt_get_tile_costs: no probe has run / bad size");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipDeviceSynchronize());
+    HIP_TRY(c, hipMemcpy(out, c->d_tile_cost, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return SRT_OK;
+}
+
 int srt_get_stats(srt_ctx *c, srt_stats *out) {
     if (!c || !out) return fail(c, SRT_ERR_INVALID, "srt_get_stats: null argument");
     HIP_TRY(c, hipSetDevice(c->device));
@@ -361,6 +372,7 @@ int srt_get_stats(srt_ctx *c, srt_stats *out) {
     memset(out, 0, sizeof(*out));
     out->rays = h[0]; out->node_visits = h[1]; out->tri_tests = h[2]; out->box_tests = h[3];
     for (int k = 0; k < 9; k++) out->util[k] = h[4 + k];
+    out->reserved[0] = h[13]; out->reserved[1] = h[14];   // instrumented: max node visits / max rays of any single pixel
     // paths = spp * pixels owned by this rank
     uint64_t pixels = 0;
     for (uint32_t t = c->rank; t < c->n_tiles; t += c->world) {

@@ -459,6 +459,23 @@ struct Builder {
         init_tri((int)s.raw.size() - 1);
         return (int)s.raw.size() - 1;
     }
+    // Mesh triangle of the SYNTHETIC scenes.  The reference's inside test projects a triangle on the plane named by its
+    // aa_plane member, which tri::init only sets for axis-aligned triangles and otherwise leaves as it was (heap garbage
+    // for a fresh triangle, tri.cuh:90; this build: an explicit input, D2).  With the XY default a facet whose normal lies
+    // near the XY plane projects to a sliver and is almost un-hittable: rays leak into a tessellated sphere and bounce
+    // inside until the bounce limit.  A mesh therefore passes, per triangle, the plane of its dominant normal axis --
+    // a value the member can legally hold -- which keeps tessellated objects watertight.
+    int tri_mesh(F3 a, F3 b, F3 c, uint32_t mat) {
+        const F3 n = cross3(sub(b, a), sub(c, a));
+        const float ax = fabsf(n.x), ay = fabsf(n.y), az = fabsf(n.z);
+        srt_tri_in t;
+        put(t.v0, a); put(t.v1, b); put(t.v2, c);
+        t.mat_index = mat;
+        t.aa_plane = (ax >= ay && ax >= az) ? SRT_AAP_YZ : ((ay >= az) ? SRT_AAP_XZ : SRT_AAP_XY);
+        s.raw.push_back(t);
+        init_tri((int)s.raw.size() - 1);
+        return (int)s.raw.size() - 1;
+    }
     // tri_quad(Q, u, v) (tri_quad.cuh:14-20): halves = tri(Q,u,v) and tri(Q+u+v, -u, -v)
     int quad(F3 q, F3 u, F3 v, uint32_t mat) {
         int first = tri_vectors(q, u, v, mat);
@@ -718,8 +735,8 @@ struct SplitMix {   // scene-layout PRNG (not on the render path)
 static void add_octahedron(Builder &B, F3 c, float r, uint32_t mat) {
     const F3 px = add(c, f3(r, 0, 0)), nx = add(c, f3(-r, 0, 0)), py = add(c, f3(0, r, 0)), ny = add(c, f3(0, -r, 0)),
              pz = add(c, f3(0, 0, r)), nz = add(c, f3(0, 0, -r));
-    B.tri_vertices(px, py, pz, mat); B.tri_vertices(py, nx, pz, mat); B.tri_vertices(nx, ny, pz, mat); B.tri_vertices(ny, px, pz, mat);
-    B.tri_vertices(py, px, nz, mat); B.tri_vertices(nx, py, nz, mat); B.tri_vertices(ny, nx, nz, mat); B.tri_vertices(px, ny, nz, mat);
+    B.tri_mesh(px, py, pz, mat); B.tri_mesh(py, nx, pz, mat); B.tri_mesh(nx, ny, pz, mat); B.tri_mesh(ny, px, pz, mat);
+    B.tri_mesh(py, px, nz, mat); B.tri_mesh(nx, py, nz, mat); B.tri_mesh(ny, nx, nz, mat); B.tri_mesh(px, ny, nz, mat);
 }
 
 static void add_icosphere(Builder &B, F3 c, float r, int subdiv, uint32_t mat) {
@@ -772,7 +789,7 @@ static void add_icosphere(Builder &B, F3 c, float r, int subdiv, uint32_t mat) {
         }
         f.swap(nf);
     }
-    for (auto &fc : f) B.tri_vertices(add(c, mul(r, v[fc.a])), add(c, mul(r, v[fc.b])), add(c, mul(r, v[fc.c])), mat);
+    for (auto &fc : f) B.tri_mesh(add(c, mul(r, v[fc.a])), add(c, mul(r, v[fc.b])), add(c, mul(r, v[fc.c])), mat);
 }
 
 // smooth synthetic reflectance drawn from the layout PRNG: sigmoid(c2 (l-peak)^2 + c0)
@@ -854,8 +871,8 @@ static void scene_mesh100k(srt_scene &s, uint64_t seed) {
     for (int iz = 0; iz < G; iz++)
         for (int ix = 0; ix < G; ix++) {
             auto P = [&](int a, int b) { return f3(x0 + cell * a, hgt[b * (G + 1) + a], z0 + cell * b); };
-            B.tri_vertices(P(ix, iz), P(ix, iz + 1), P(ix + 1, iz), 3);
-            B.tri_vertices(P(ix + 1, iz), P(ix, iz + 1), P(ix + 1, iz + 1), 3);
+            B.tri_mesh(P(ix, iz), P(ix, iz + 1), P(ix + 1, iz), 3);
+            B.tri_mesh(P(ix + 1, iz), P(ix, iz + 1), P(ix + 1, iz + 1), 3);
         }
 }
 

@@ -19,9 +19,29 @@ namespace srt {
 // LDS map of one workgroup (W waves): [0, 1536) colour matching rows (96 float4) | [1536, 2304) background pairs
 // (96 float2) | inner-record cache: three float4 planes + one (16-bit refs) or two u32 planes of n_cached entries |
 // W traversal stacks, each stack_depth * 64 lanes * (2 or 4) B, lane-interleaved.
+constexpr int kLdsUniF4 = 16;          // 256 B block of launch-uniform values that only the cold paths read (see LdsUniforms)
 constexpr int kLdsCmfF4 = 96;
 constexpr int kLdsBgF2 = 96;
-constexpr int kLdsTablesF4 = kLdsCmfF4 + kLdsBgF2 / 2;
+constexpr int kLdsTablesF4 = kLdsUniF4 + kLdsCmfF4 + kLdsBgF2 / 2;
+
+// Launch-uniform values used only by the pixel-switch / camera-ray blocks.  Kept in LDS instead of SGPRs: the persistent
+// loop has ~190 live scalars otherwise, and the allocator spilled 80 of them into VGPR lanes, putting dozens of
+// v_readlane into every traversal step.  A uniform-address ds_read is a broadcast and is only paid in the cold blocks.
+struct LdsUniforms {
+    float du[3], dv[3], p00[3], center[3], disk_u[3], disk_v[3], defocus_angle;
+    uint32_t width, height, offx, offy, tx, ty, bx, by, tiles_x, n_tiles, rank, world, spp, n_lanes;
+    uint32_t sched[3];
+    uint32_t rng[2], tile_out[2], tile_order[2], tile_cost[2], pixel_counter[2];
+};
+static_assert(sizeof(LdsUniforms) <= kLdsUniF4 * 16, "uniform block too large");
+typedef __attribute__((address_space(3))) LdsUniforms lds_uniforms;
+__device__ __forceinline__ void split_ptr(const void *p, __attribute__((address_space(3))) uint32_t *dst) {
+    const unsigned long long v = (unsigned long long)p;
+    dst[0] = (uint32_t)v; dst[1] = (uint32_t)(v >> 32);
+}
+template <typename T>
+__device__ __forceinline__ T *join_ptr(uint32_t lo, uint32_t hi) { return reinterpret_cast<T *>(((unsigned long long)hi << 32) | lo); }
+
 constexpr size_t kLdsBudget = 160 * 1024;
 static inline size_t round16(size_t v) { return (v + 15) & ~(size_t)15; }
 static inline bool narrow_refs(int n_records) { return n_records <= 65535; }
@@ -89,8 +109,9 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
     constexpr bool PROBE = (MODE == 2);
     constexpr bool ITERS = COUNT || PROBE;
     extern __shared__ float4 lds4[];
-    float4 *s_cmf = lds4;
-    float2 *s_bg = reinterpret_cast<float2 *>(lds4 + kLdsCmfF4);
+    lds_uniforms *U = (lds_uniforms *)lds4;
+    float4 *s_cmf = lds4 + kLdsUniF4;
+    float2 *s_bg = reinterpret_cast<float2 *>(lds4 + kLdsUniF4 + kLdsCmfF4);
     const bool narrow = P.n_records <= 65535;
     const uint32_t nc = (uint32_t)P.n_cached;
     float4 *s_q0 = lds4 + kLdsTablesF4, *s_q1 = s_q0 + nc, *s_q2 = s_q1 + nc;
@@ -100,6 +121,19 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
 
+    if (threadIdx.x == 0) {
+        for (int a = 0; a < 3; a++) {
+            U->du[a] = P.du[a]; U->dv[a] = P.dv[a]; U->p00[a] = P.p00[a]; U->center[a] = P.center[a];
+            U->disk_u[a] = P.disk_u[a]; U->disk_v[a] = P.disk_v[a];
+            U->sched[a] = P.sched ? P.sched[a] : 0u;
+        }
+        U->defocus_angle = P.defocus_angle;
+        U->width = P.width; U->height = P.height; U->offx = P.offx; U->offy = P.offy;
+        U->tx = P.tx; U->ty = P.ty; U->bx = P.bx; U->by = P.by;
+        U->tiles_x = P.tiles_x; U->n_tiles = P.n_tiles; U->rank = P.rank; U->world = P.world; U->spp = P.spp; U->n_lanes = P.n_lanes;
+        split_ptr(P.rng, U->rng); split_ptr(P.tile_out, U->tile_out); split_ptr(P.tile_order, U->tile_order);
+        split_ptr(P.tile_cost, U->tile_cost); split_ptr(P.pixel_counter, U->pixel_counter);
+    }
     for (uint32_t k = threadIdx.x; k < kLdsCmfF4; k += blockDim.x) s_cmf[k] = P.cmf[k];
     for (uint32_t k = threadIdx.x; k < kLdsBgF2; k += blockDim.x) s_bg[k] = P.bg_sd[k];
     for (uint32_t k = threadIdx.x; k < nc; k += blockDim.x) {
@@ -117,9 +151,8 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
     ns.lds_r0 = (lds_cu32 *)s_r0; ns.lds_r1 = (lds_cu32 *)s_r1;
     ns.n_cached = P.n_cached; ns.refs16 = narrow;
     const buf_rsrc tri_rsrc = make_rsrc(P.tris, P.n_tris * 48u);
-    const V3 du = mk(P.du[0], P.du[1], P.du[2]), dv = mk(P.dv[0], P.dv[1], P.dv[2]);
-    const V3 cam_center = mk(P.center[0], P.center[1], P.center[2]);
     const uint32_t n_local_pixels = P.tiles_local * 64u;
+    const uint32_t spp = P.spp;
     StackRef my_stack;
     {
         const size_t depth = (size_t)(P.stack_depth < 1 ? 1 : P.stack_depth);
@@ -144,9 +177,13 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
     Trav tv; tv.node = -1; tv.sp = 0; tv.c = kFltMax; tv.hit = -1;
     uint32_t n_rays = 0;
     TravStats ts;
+    // latency mode (see the traversal phase): cost class of this lane's pixel, from the probe
+    uint32_t lane_class = 0;
+    uint32_t wave_class = ~0u;
     unsigned long long t_shade = 0, t_inner = 0, t_fringe = 0, t_mark = 0;   // instrumented build: wave cycles per phase
     if (COUNT) t_mark = __builtin_amdgcn_s_memtime();
-    uint32_t cur_tile_local = 0, pixel_iters0 = 0;   // probe only
+    uint32_t cur_tile_local = 0, pixel_iters0 = 0;   // probe / instrumented builds
+    uint32_t pixel_rays0 = 0, max_pix_iters = 0, max_pix_rays = 0;
 
     for (;;) {
         // =========================== shading phase ===========================================================
@@ -266,28 +303,29 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
             }
 
             // ---- S3: pixel switch: all samples of the current pixel done (or no pixel yet) ------------------------
-            if (!dead && tv.node < 0 && !have_path && !begin_trav && (!have_pixel || sample == P.spp)) {
+            if (!dead && tv.node < 0 && !have_path && !begin_trav && (!have_pixel || sample == spp)) {
                 if (have_pixel && PROBE) {
                     // cost of this pixel = node records it visited (+1 so that empty pixels still sort after real ones)
-                    atomicAdd(&P.tile_cost[cur_tile_local], ts.n_iters - pixel_iters0 + 1u);
+                    atomicAdd(join_ptr<uint32_t>(U->tile_cost[0], U->tile_cost[1]) + cur_tile_local, ts.n_iters - pixel_iters0 + 1u);
                     have_pixel = false;
                 }
+                if (have_pixel && COUNT) { max_pix_iters = max(max_pix_iters, ts.n_iters - pixel_iters0); max_pix_rays = max(max_pix_rays, n_rays - pixel_rays0); }
                 if (have_pixel && !PROBE) {
                     // store RNG state (rendering.cu:232) and save_to_fb (rendering.cu:140-149)
-                    P.rng[0 * (size_t)P.n_lanes + idx] = rs.d;
-                    P.rng[1 * (size_t)P.n_lanes + idx] = rs.v0;
-                    P.rng[2 * (size_t)P.n_lanes + idx] = rs.v1;
-                    P.rng[3 * (size_t)P.n_lanes + idx] = rs.v2;
-                    P.rng[4 * (size_t)P.n_lanes + idx] = rs.v3;
-                    P.rng[5 * (size_t)P.n_lanes + idx] = rs.v4;
+                    {
+                        uint32_t *rng = join_ptr<uint32_t>(U->rng[0], U->rng[1]);
+                        const size_t nl = U->n_lanes;
+                        rng[0 * nl + idx] = rs.d; rng[1 * nl + idx] = rs.v0; rng[2 * nl + idx] = rs.v1;
+                        rng[3 * nl + idx] = rs.v2; rng[4 * nl + idx] = rs.v3; rng[5 * nl + idx] = rs.v4;
+                    }
                     // pixel_color / float(spp) -> (1/spp) * v ; XYZ_to_sRGB (color.cu:35-41, vec3.cuh:80-91)
-                    const float inv_spp = 1.0f / (float)P.spp;
+                    const float inv_spp = 1.0f / (float)spp;
                     const V3 c = inv_spp * acc;
                     const float r_lin = (3.2404542f * c.x) + (-1.5371385f * c.y) + (-0.4985314f * c.z);
                     const float g_lin = (-0.9692660f * c.x) + (1.8760108f * c.y) + (0.0415560f * c.z);
                     const float b_lin = (0.0556434f * c.x) + (-0.2040259f * c.y) + (1.0572252f * c.z);
                     const float r = correct_channel(r_lin), g = correct_channel(g_lin), b = correct_channel(b_lin);
-                    float *o = P.tile_out + out_slot;
+                    float *o = join_ptr<float>(U->tile_out[0], U->tile_out[1]) + out_slot;
                     o[0 * kTileLanes] = (float)(int)(r * 255.99f);      // expand_sRGB (color.cu:43-49, Q15)
                     o[1 * kTileLanes] = (float)(int)(g * 255.99f);
                     o[2 * kTileLanes] = (float)(int)(b * 255.99f);
@@ -301,32 +339,38 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
                     const unsigned long long m = __ballot(1);
                     const int leader = __ffsll((long long)m) - 1;
                     uint32_t base = 0;
-                    if ((int)lane == leader) base = atomicAdd(P.pixel_counter, (uint32_t)__popcll(m));
+                    if ((int)lane == leader) base = atomicAdd(join_ptr<uint32_t>(U->pixel_counter[0], U->pixel_counter[1]), (uint32_t)__popcll(m));
                     base = (uint32_t)__shfl((int)base, leader, 64);
                     const uint32_t pix = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
                     if (pix >= n_local_pixels) { dead = true; searching = false; }
                     else {
-                        const uint32_t tile_local = P.tile_order ? P.tile_order[pix >> 6] : (pix >> 6);   // cost-ordered queue
+                        const uint32_t *tile_order = join_ptr<const uint32_t>(U->tile_order[0], U->tile_order[1]);
+                        const uint32_t tile_local = tile_order ? tile_order[pix >> 6] : (pix >> 6);   // cost-ordered queue
+                        lane_class = (pix >> 6) < U->sched[0] ? 3u : ((pix >> 6) < U->sched[1] ? 2u : ((pix >> 6) < U->sched[2] ? 1u : 0u));
                         const uint32_t lt = pix & 63u;
-                        const uint32_t tile = P.rank + P.world * tile_local;
-                        const uint32_t tile_x = tile % P.tiles_x, tile_y = tile / P.tiles_x;
+                        const uint32_t tile = U->rank + U->world * tile_local;
+                        const uint32_t tiles_x = U->tiles_x;
+                        const uint32_t tile_x = tile % tiles_x, tile_y = tile / tiles_x;
                         const uint32_t i = tile_x * 8u + (lt & 7u);          // chunk-relative column (rendering.cu:156)
                         const uint32_t j = tile_y * 8u + (lt >> 3);          // chunk-relative row    (rendering.cu:157)
+                        const uint32_t gtx = U->tx, gty = U->ty, gbx = U->bx;
                         // pixels outside the chunk (or the reference grid) never touch RNG or output (rendering.cu:205)
-                        if ((tile < P.n_tiles) && (i < P.width) && (j < P.height) && (i / P.tx < P.bx) && (j / P.ty < P.by)) {
-                            idx = block_linear_idx(i, j, P.tx, P.ty, P.bx);
+                        if ((tile < U->n_tiles) && (i < U->width) && (j < U->height) && (i / gtx < gbx) && (j / gty < U->by)) {
+                            idx = block_linear_idx(i, j, gtx, gty, gbx);
                             out_slot = tile_local * (uint32_t)(kTilePlanes * kTileLanes) + lt;
                             // pixel_center = p00 + (float)i*du + (float)j*dv, i/j incl. the chunk offset (rendering.cu:76,221)
-                            pixel_center = (mk(P.p00[0], P.p00[1], P.p00[2]) + (float)(P.offx + i) * du) + (float)(P.offy + j) * dv;
-                            rs.d = P.rng[0 * (size_t)P.n_lanes + idx];      // rendering.cu:209
-                            rs.v0 = P.rng[1 * (size_t)P.n_lanes + idx];
-                            rs.v1 = P.rng[2 * (size_t)P.n_lanes + idx];
-                            rs.v2 = P.rng[3 * (size_t)P.n_lanes + idx];
-                            rs.v3 = P.rng[4 * (size_t)P.n_lanes + idx];
-                            rs.v4 = P.rng[5 * (size_t)P.n_lanes + idx];
+                            const V3 du = mk(U->du[0], U->du[1], U->du[2]), dv = mk(U->dv[0], U->dv[1], U->dv[2]);
+                            pixel_center = (mk(U->p00[0], U->p00[1], U->p00[2]) + (float)(U->offx + i) * du) + (float)(U->offy + j) * dv;
+                            {
+                                const uint32_t *rng = join_ptr<const uint32_t>(U->rng[0], U->rng[1]);      // rendering.cu:209
+                                const size_t nl = U->n_lanes;
+                                rs.d = rng[0 * nl + idx]; rs.v0 = rng[1 * nl + idx]; rs.v1 = rng[2 * nl + idx];
+                                rs.v2 = rng[3 * nl + idx]; rs.v3 = rng[4 * nl + idx]; rs.v4 = rng[5 * nl + idx];
+                            }
                             acc = mk(0.f, 0.f, 0.f);
                             sample = 0;
                             if (PROBE) { cur_tile_local = tile_local; pixel_iters0 = ts.n_iters; }
+                            if (COUNT) { pixel_iters0 = ts.n_iters; pixel_rays0 = n_rays; }
                             have_pixel = true;
                             searching = false;
                         }
@@ -335,20 +379,22 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
             }
 
             // ---- S4: new camera ray: renderer::get_ray (rendering.cu:66-87) ----------------------------------------
-            if (!dead && tv.node < 0 && !have_path && !begin_trav && have_pixel && sample < P.spp) {
+            if (!dead && tv.node < 0 && !have_path && !begin_trav && have_pixel && sample < spp) {
                 float px = -0.5f + rng_uniform(rs);                       // pixel_sample_square, :49-56
                 float py = -0.5f + rng_uniform(rs);
+                const V3 du = mk(U->du[0], U->du[1], U->du[2]), dv = mk(U->dv[0], U->dv[1], U->dv[2]);
+                const V3 cam_center = mk(U->center[0], U->center[1], U->center[2]);
                 V3 pixel_sample = pixel_center + (px * du + py * dv);
                 V3 origin = cam_center;
-                if (!(P.defocus_angle <= 0.0f)) {                          // defocus_disk_sample, :42-47
+                if (!(U->defocus_angle <= 0.0f)) {                          // defocus_disk_sample, :42-47
                     float dx, dy;
                     for (;;) {                                             // random_in_unit_disk, vec3.cuh:240-246
                         dx = rng_range(rs, -1.0f, 1.0f);
                         dy = rng_range(rs, -1.0f, 1.0f);
                         if ((dx * dx + dy * dy) + 0.0f * 0.0f < 1.0f) break;
                     }
-                    origin = (cam_center + dx * mk(P.disk_u[0], P.disk_u[1], P.disk_u[2])) +
-                             dy * mk(P.disk_v[0], P.disk_v[1], P.disk_v[2]);
+                    origin = (cam_center + dx * mk(U->disk_u[0], U->disk_u[1], U->disk_u[2])) +
+                             dy * mk(U->disk_v[0], U->disk_v[1], U->disk_v[2]);
                 }
                 ro = origin;
                 rd = pixel_sample - origin;                                // not normalised (Q10)
@@ -379,12 +425,28 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
         // P.fringe_threshold of them can share one fringe step, or until no lane has inner work left.
         const unsigned long long alive_mask = __ballot(!dead);
         if (alive_mask == 0ull) break;
+        // Latency mode.  A pixel is one sequential chain (its RNG stream), so the launch cannot end before its most expensive
+        // pixel does -- at cfg 3 one pixel needs 678 k node visits, 11x the mean.  Waves that hold expensive pixels (cost class
+        // from the probe) therefore trade throughput for latency: they raise their issue priority over the other waves of
+        // the SIMD and stop batching (the shade / fringe thresholds shrink to 1 for the top class).
+        {
+            const uint32_t wc = __ballot(!dead && lane_class == 3u) ? 3u : (__ballot(!dead && lane_class >= 2u) ? 2u : (__ballot(!dead && lane_class >= 1u) ? 1u : 0u));
+            if (wc != wave_class) {
+                wave_class = wc;
+                if (wc == 3u) __builtin_amdgcn_s_setprio(3);
+                else if (wc == 2u) __builtin_amdgcn_s_setprio(2);
+                else if (wc == 1u) __builtin_amdgcn_s_setprio(1);
+                else __builtin_amdgcn_s_setprio(0);
+            }
+        }
+        const int shade_thr = wave_class == 3u ? 1 : (wave_class == 2u ? max(1, (int)P.shade_threshold / 8) : (wave_class == 1u ? max(1, (int)P.shade_threshold / 2) : (int)P.shade_threshold));
+        const int fringe_thr = wave_class == 3u ? 1 : (wave_class == 2u ? max(1, (int)P.fringe_threshold / 8) : (wave_class == 1u ? max(1, (int)P.fringe_threshold / 2) : (int)P.fringe_threshold));
         for (;;) {
             const unsigned long long trav_mask = __ballot(tv.node >= 0);
             if (trav_mask == 0ull) break;
-            if (__popcll(alive_mask & ~trav_mask) >= (int)P.shade_threshold) break;
+            if (__popcll(alive_mask & ~trav_mask) >= shade_thr) break;
             const unsigned long long fringe_mask = __ballot(tv.node >= P.n_inner);
-            const bool do_fringe = (__popcll(fringe_mask) >= (int)P.fringe_threshold) || (fringe_mask == trav_mask);
+            const bool do_fringe = (__popcll(fringe_mask) >= fringe_thr) || (fringe_mask == trav_mask);
             if (COUNT) { ts.w_iters++; ts.w_alive += (uint32_t)__popcll(alive_mask); if (do_fringe) { ts.w_fringe++; ts.l_fringe += (uint32_t)__popcll(fringe_mask); } else ts.l_inner += (uint32_t)__popcll(trav_mask & ~fringe_mask); }
             if (do_fringe) {
                 if (tv.node >= P.n_inner) {
@@ -421,6 +483,10 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
                 atomicAdd(&P.counters[8], (unsigned long long)ts.l_fringe);
                 atomicAdd(&P.counters[9], (unsigned long long)ts.l_inner);
                 atomicAdd(&P.counters[10], t_shade);
+            }
+            atomicMax(&P.counters[13], (unsigned long long)max_pix_iters);
+            atomicMax(&P.counters[14], (unsigned long long)max_pix_rays);
+            if (lane == 0) {
                 atomicAdd(&P.counters[11], t_inner);
                 atomicAdd(&P.counters[12], t_fringe);
             }
@@ -431,18 +497,28 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
 // Cost-descending order of the local tiles for the pixel queue (longest-processing-time-first), on the device so that
 // srt_render_chunk never has to synchronise with the host: one workgroup, 4096-bin counting sort on the probe's per-tile
 // cost.  The order inside a bin is arbitrary -- it only affects scheduling, never results.
-__global__ __launch_bounds__(1024) void order_tiles_kernel(const uint32_t *__restrict__ cost, uint32_t *__restrict__ order, uint32_t n) {
+__global__ __launch_bounds__(1024) void order_tiles_kernel(const uint32_t *__restrict__ cost, uint32_t *__restrict__ order, uint32_t n,
+                                                          uint32_t *__restrict__ sched) {
     constexpr uint32_t kBinsN = 4096;
     __shared__ uint32_t s_bin[kBinsN];
     __shared__ uint32_t s_max;
+    __shared__ unsigned long long s_sum;
+    __shared__ uint32_t s_cls[3];
     const uint32_t t = threadIdx.x;
-    if (t == 0) s_max = 1u;
+    if (t == 0) { s_max = 1u; s_sum = 0ull; s_cls[0] = s_cls[1] = s_cls[2] = 0u; }
     for (uint32_t b = t; b < kBinsN; b += 1024) s_bin[b] = 0u;
     __syncthreads();
     uint32_t m = 0;
-    for (uint32_t k = t; k < n; k += 1024) m = max(m, cost[k]);
+    unsigned long long sum = 0;
+    for (uint32_t k = t; k < n; k += 1024) { m = max(m, cost[k]); sum += cost[k]; }
     atomicMax(&s_max, m);
+    atomicAdd(&s_sum, sum);
     __syncthreads();
+    // cost classes for the latency mode of the render kernel: tiles costing >= 8x / 4x / 2x the mean tile
+    const unsigned long long mean = s_sum / (n ? n : 1u) + 1ull;
+    uint32_t c3 = 0, c2 = 0, c1 = 0;
+    for (uint32_t k = t; k < n; k += 1024) { const unsigned long long c = cost[k]; c3 += c >= 8 * mean; c2 += c >= 4 * mean; c1 += c >= 2 * mean; }
+    atomicAdd(&s_cls[0], c3); atomicAdd(&s_cls[1], c2); atomicAdd(&s_cls[2], c1);
     const float scale = (float)(kBinsN - 1) / (float)s_max;
     auto bin_of = [&](uint32_t c) { uint32_t b = (uint32_t)((float)c * scale); b = b > kBinsN - 1 ? kBinsN - 1 : b; return (kBinsN - 1) - b; };   // bin 0 = most expensive
     for (uint32_t k = t; k < n; k += 1024) atomicAdd(&s_bin[bin_of(cost[k])], 1u);
@@ -453,6 +529,8 @@ __global__ __launch_bounds__(1024) void order_tiles_kernel(const uint32_t *__res
     }
     __syncthreads();
     for (uint32_t k = t; k < n; k += 1024) order[atomicAdd(&s_bin[bin_of(cost[k])], 1u)] = k;
+    // queue positions below sched[i] belong to class 3 - i (the queue is cost-descending up to the bin width)
+    if (t == 0) { sched[0] = s_cls[0]; sched[1] = s_cls[1]; sched[2] = s_cls[2]; }
 }
 
 // Gathered compact tiles -> block-linear planar framebuffer (rendering.cu:146-148 layout).
@@ -597,9 +675,9 @@ hipError_t launch_render(const RenderParams &p, uint32_t n_cu, int mode, hipStre
     return launch_render_mode<0>(p, n_cu, st);
 }
 
-hipError_t launch_order_tiles(const uint32_t *cost, uint32_t *order, uint32_t n, hipStream_t st) {
+hipError_t launch_order_tiles(const uint32_t *cost, uint32_t *order, uint32_t n, uint32_t *sched, hipStream_t st) {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(order_tiles_kernel, dim3(1), dim3(1024), 0, st, cost, order, n);
+    hipLaunchKernelGGL(order_tiles_kernel, dim3(1), dim3(1024), 0, st, cost, order, n, sched);
     return hipGetLastError();
 }
 

@@ -96,11 +96,18 @@ class Renderer:
         self._ck(B.lib().srt_read_fb_rowmajor(self._h, B.fptr(r), B.fptr(g), B.fptr(b), image_width, image_height))
         return r, g, b
 
+    def tile_costs(self):
+        _, _, tl, _ = self.tile_buffer()
+        out = np.zeros(tl, np.uint32)
+        self._ck(B.lib().srt_get_tile_costs(self._h, out.ctypes.data_as(C.POINTER(C.c_uint32)), tl))
+        return out
+
     def stats(self):
         st = B.Stats()
         self._ck(B.lib().srt_get_stats(self._h, C.byref(st)))
         d = {k: getattr(st, k) for k in ("rays", "paths", "node_visits", "tri_tests", "box_tests")}
         d["util"] = list(st.util)
+        d["max_pixel_node_visits"], d["max_pixel_rays"] = st.reserved[0], st.reserved[1]
         return d
 
     def last_kernel_ms(self):

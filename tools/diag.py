@@ -9,11 +9,12 @@ ap.add_argument("--scene", type=int, default=100); ap.add_argument("--bvh", type
 ap.add_argument("--width", type=int, default=1920); ap.add_argument("--height", type=int, default=1080)
 ap.add_argument("--spp", type=int, default=16); ap.add_argument("--depth", type=int, default=16)
 ap.add_argument("--reps", type=int, default=2)
+ap.add_argument("--world", type=int, default=1); ap.add_argument("--rank", type=int, default=0)
 a = ap.parse_args()
 scene = srt.Scene.builtin(a.scene, 0).build_bvh(a.bvh, 1984)
 cam = scene.default_camera(a.width, a.height)
 r = srt.Renderer(0)
-r.upload_scene(scene); r.set_camera(cam); r.set_partition(0, 1)
+r.upload_scene(scene); r.set_camera(cam); r.set_partition(a.rank, a.world)
 res = {"tris": scene.n_tris, "nodes": scene.n_nodes, "depth": scene.bvh_depth}
 for count in (True, False):
     r.set_count_traversal(count)
@@ -29,7 +30,7 @@ for count in (True, False):
         res.update(rays=st["rays"], rays_per_path=st["rays"] / st["paths"], V=st["node_visits"] / st["rays"], T=st["tri_tests"] / st["rays"],
                    Bx=st["box_tests"] / st["rays"],
                    trav_simd_util=st["node_visits"] / (64.0 * u[0]), alive_frac=u[1] / (64.0 * u[0]), trav_over_alive=st["node_visits"] / max(u[1], 1), nan_ray_frac=u[2] / st["rays"], fringe_steps_frac=u[3] / max(u[0], 1), fringe_lane_util=u[4] / (64.0 * max(u[3], 1)), inner_lane_util=u[5] / (64.0 * max(u[0] - u[3], 1)), cycles_shade_inner_fringe=[u[6] / max(u[6] + u[7] + u[8], 1), u[7] / max(u[6] + u[7] + u[8], 1), u[8] / max(u[6] + u[7] + u[8], 1)],
-                   cyc_per_inner_step=u[7] / max(u[0] - u[3], 1), cyc_per_fringe_step=u[8] / max(u[3], 1), ms_instrumented=best)
+                   cyc_per_inner_step=u[7] / max(u[0] - u[3], 1), cyc_per_fringe_step=u[8] / max(u[3], 1), max_pixel_node_visits=st["max_pixel_node_visits"], max_pixel_rays=st["max_pixel_rays"], mean_pixel_node_visits=st["node_visits"] / (a.width * a.height / a.world), ms_instrumented=best)
     else:
         res.update(ms=best, mray_s=st["rays"] / best / 1e3)
 print(json.dumps(res, indent=1))
