@@ -40,7 +40,8 @@ struct srt_ctx {
     int n_cu = 256;
     uint32_t fringe_threshold = 20;                    // env SRT_FRINGE_THRESHOLD
     uint32_t shade_threshold = 32, waves_per_cu = 0;   // tuning knobs (env SRT_SHADE_THRESHOLD / SRT_WAVES_PER_CU)
-    bool latency_mode = true;                          // env SRT_LATENCY_MODE=0 disables priorities / threshold scaling
+    uint32_t debug_lane_limit = 0;                     // env SRT_DEBUG_LANE_LIMIT (experiments: partial tiles)
+    bool latency_mode = false;                          // experimental (env SRT_LATENCY_MODE=1): wave priorities / threshold scaling by tile cost class
     uint32_t probe_spp = 2;                            // samples of the cost probe (env SRT_PROBE_SPP, 0 = no ordering)
     uint32_t *d_tile_cost = nullptr, *d_tile_order = nullptr;
     size_t tile_sched_capacity = 0;
@@ -115,6 +116,7 @@ int srt_create(int device, srt_ctx **out) {
     if (const char *ev = getenv("SRT_SHADE_THRESHOLD")) c->shade_threshold = (uint32_t)std::max(1, atoi(ev));
     if (const char *ev = getenv("SRT_WAVES_PER_CU")) c->waves_per_cu = (uint32_t)std::max(0, atoi(ev));
     if (const char *ev = getenv("SRT_PROBE_SPP")) c->probe_spp = (uint32_t)std::max(0, atoi(ev));
+    if (const char *ev = getenv("SRT_DEBUG_LANE_LIMIT")) c->debug_lane_limit = (uint32_t)std::max(0, atoi(ev));
     if (const char *ev = getenv("SRT_LATENCY_MODE")) c->latency_mode = atoi(ev) != 0;
     if (const char *ev = getenv("SRT_FRINGE_THRESHOLD")) c->fringe_threshold = (uint32_t)std::max(1, atoi(ev));
     {
@@ -238,7 +240,7 @@ int srt_render_chunk(srt_ctx *c, uint32_t width, uint32_t height, uint32_t offx,
     // A pixel is one sequential RNG stream, so the launch cannot finish before its most expensive pixel does.  A short
     // probe (probe_spp samples per pixel from a copy of the RNG state, nothing written) measures the traversal cost of
     // every tile; the queue then hands tiles out in descending cost order (longest-processing-time-first).
-    p.tile_order = nullptr; p.tile_cost = nullptr; p.sched = nullptr;
+    p.tile_order = nullptr; p.tile_cost = nullptr; p.sched = nullptr; p.debug_lane_limit = c->debug_lane_limit;
     const bool ordered = c->probe_spp > 0 && c->spp > 4 * c->probe_spp && c->tiles_local > 1;
     if (ordered) {
         if (c->tiles_local > c->tile_sched_capacity) {

@@ -215,6 +215,7 @@ struct TravStats {
 struct Trav {
     int node;        // >= 0: record to visit next; < 0: not traversing
     int sp;          // stack entries in use
+    int top;         // the newest stack entry lives in a register (valid iff sp > 0); LDS holds entries 0 .. sp-2
     float c;         // closest_so_far
     int hit;         // triangle of the closest hit or -1
 };
@@ -222,7 +223,7 @@ struct Trav {
 // Start a closest-hit query (bvh.cu:101-119).  Returns true when the query is already finished (leaf root).
 template <bool COUNT>
 __device__ __forceinline__ bool trav_begin(Trav &tv, const float4 *__restrict__ tris, int root_ref, V3 o, V3 d, TravStats &ts) {
-    tv.c = kFltMax; tv.hit = -1; tv.sp = 0;
+    tv.c = kFltMax; tv.hit = -1; tv.sp = 0; tv.top = -1;
     // A direction with a NaN component can never hit anything: every product with it is NaN (0*NaN included), so
     // dot(n, dir) is NaN, `fabs(denom) < 1e-8` is false, t = x/NaN is NaN and `0 <= t` is false for EVERY triangle
     // (tri.cu:12-23), while every box test passes (all comparisons false, aabb.cu:30-36).  The reference therefore
@@ -341,13 +342,24 @@ __device__ __forceinline__ void box_pair(const f4v &q0, const f4v &q1, const f4v
     m_l = fminf(fminf(t1x.x, t1y.x), t1z.x); m_r = fminf(fminf(t1x.y, t1y.y), t1z.y);
 }
 
+// bvh.cu:154-160: pop when neither child is to be traversed; otherwise descend left first and push right iff both.
+// The newest entry is kept in a register: a pop hands it out immediately and re-fills the register with an LDS read
+// whose result is not needed before the NEXT pop or push, so the LDS latency leaves the critical path of the step.
 __device__ __forceinline__ void trav_advance(Trav &tv, bool trav_l, bool trav_r, int lref, int rref, const StackRef &stack) {
-    if (!trav_l && !trav_r) {                       // bvh.cu:154-155: pop
+    if (!trav_l && !trav_r) {
         if (tv.sp == 0) tv.node = -1;
-        else { tv.sp--; tv.node = stack_pop(stack, tv.sp); }
-    } else {                                        // bvh.cu:156-160: descend left first, push right iff both
+        else {
+            tv.node = tv.top;
+            tv.sp--;
+            if (tv.sp > 0) tv.top = stack_pop(stack, tv.sp - 1);
+        }
+    } else {
         tv.node = trav_l ? lref : rref;
-        if (trav_l && trav_r) { stack_push(stack, tv.sp, rref); tv.sp++; }
+        if (trav_l && trav_r) {
+            if (tv.sp > 0) stack_push(stack, tv.sp - 1, tv.top);
+            tv.top = rref;
+            tv.sp++;
+        }
     }
 }
 

@@ -44,6 +44,7 @@ struct RenderParams {
     uint32_t *tile_cost;                  // probe mode: per local tile, node records visited by its pixels
     const uint32_t *sched;                // optional: queue positions below sched[0] / [1] / [2] are cost class 3 / 2 / 1
     uint32_t waves_per_cu_override;       // 0 = occupancy API
+    uint32_t debug_lane_limit;            // experiments only (env SRT_DEBUG_LANE_LIMIT): lanes >= limit of every tile stay idle
     // state / outputs
     uint32_t *rng;                        // SoA: 6 planes of n_lanes words, indexed by the block-linear idx
     uint32_t n_lanes;                     // tx*ty*bx*by

@@ -31,6 +31,7 @@ struct LdsUniforms {
     float du[3], dv[3], p00[3], center[3], disk_u[3], disk_v[3], defocus_angle;
     uint32_t width, height, offx, offy, tx, ty, bx, by, tiles_x, n_tiles, rank, world, spp, n_lanes;
     uint32_t sched[3];
+    uint32_t lane_limit;
     uint32_t rng[2], tile_out[2], tile_order[2], tile_cost[2], pixel_counter[2];
 };
 static_assert(sizeof(LdsUniforms) <= kLdsUniF4 * 16, "uniform block too large");
@@ -128,6 +129,7 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
             U->sched[a] = P.sched ? P.sched[a] : 0u;
         }
         U->defocus_angle = P.defocus_angle;
+        U->lane_limit = P.debug_lane_limit ? P.debug_lane_limit : 64u;
         U->width = P.width; U->height = P.height; U->offx = P.offx; U->offy = P.offy;
         U->tx = P.tx; U->ty = P.ty; U->bx = P.bx; U->by = P.by;
         U->tiles_x = P.tiles_x; U->n_tiles = P.n_tiles; U->rank = P.rank; U->world = P.world; U->spp = P.spp; U->n_lanes = P.n_lanes;
@@ -174,7 +176,7 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
     float pw[kWavelengths];
 #pragma unroll
     for (int k = 0; k < kWavelengths; k++) pw[k] = 0.f;
-    Trav tv; tv.node = -1; tv.sp = 0; tv.c = kFltMax; tv.hit = -1;
+    Trav tv; tv.node = -1; tv.sp = 0; tv.top = -1; tv.c = kFltMax; tv.hit = -1;
     uint32_t n_rays = 0;
     TravStats ts;
     // latency mode (see the traversal phase): cost class of this lane's pixel, from the probe
@@ -344,10 +346,11 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
                     const uint32_t pix = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
                     if (pix >= n_local_pixels) { dead = true; searching = false; }
                     else {
+                        const uint32_t qp = pix;
                         const uint32_t *tile_order = join_ptr<const uint32_t>(U->tile_order[0], U->tile_order[1]);
-                        const uint32_t tile_local = tile_order ? tile_order[pix >> 6] : (pix >> 6);   // cost-ordered queue
-                        lane_class = (pix >> 6) < U->sched[0] ? 3u : ((pix >> 6) < U->sched[1] ? 2u : ((pix >> 6) < U->sched[2] ? 1u : 0u));
-                        const uint32_t lt = pix & 63u;
+                        const uint32_t tile_local = tile_order ? tile_order[qp >> 6] : (qp >> 6);   // cost-ordered queue
+                        lane_class = (qp >> 6) < U->sched[0] ? 3u : ((qp >> 6) < U->sched[1] ? 2u : ((qp >> 6) < U->sched[2] ? 1u : 0u));
+                        const uint32_t lt = qp & 63u;
                         const uint32_t tile = U->rank + U->world * tile_local;
                         const uint32_t tiles_x = U->tiles_x;
                         const uint32_t tile_x = tile % tiles_x, tile_y = tile / tiles_x;
@@ -355,7 +358,7 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
                         const uint32_t j = tile_y * 8u + (lt >> 3);          // chunk-relative row    (rendering.cu:157)
                         const uint32_t gtx = U->tx, gty = U->ty, gbx = U->bx;
                         // pixels outside the chunk (or the reference grid) never touch RNG or output (rendering.cu:205)
-                        if ((tile < U->n_tiles) && (i < U->width) && (j < U->height) && (i / gtx < gbx) && (j / gty < U->by)) {
+                        if ((tile < U->n_tiles) && (lt < U->lane_limit) && (i < U->width) && (j < U->height) && (i / gtx < gbx) && (j / gty < U->by)) {
                             idx = block_linear_idx(i, j, gtx, gty, gbx);
                             out_slot = tile_local * (uint32_t)(kTilePlanes * kTileLanes) + lt;
                             // pixel_center = p00 + (float)i*du + (float)j*dv, i/j incl. the chunk offset (rendering.cu:76,221)
@@ -439,8 +442,15 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
                 else __builtin_amdgcn_s_setprio(0);
             }
         }
-        const int shade_thr = wave_class == 3u ? 1 : (wave_class == 2u ? max(1, (int)P.shade_threshold / 8) : (wave_class == 1u ? max(1, (int)P.shade_threshold / 2) : (int)P.shade_threshold));
-        const int fringe_thr = wave_class == 3u ? 1 : (wave_class == 2u ? max(1, (int)P.fringe_threshold / 8) : (wave_class == 1u ? max(1, (int)P.fringe_threshold / 2) : (int)P.fringe_threshold));
+        int shade_thr = wave_class == 3u ? 1 : (wave_class == 2u ? max(1, (int)P.shade_threshold / 8) : (wave_class == 1u ? max(1, (int)P.shade_threshold / 2) : (int)P.shade_threshold));
+        int fringe_thr = wave_class == 3u ? 1 : (wave_class == 2u ? max(1, (int)P.fringe_threshold / 8) : (wave_class == 1u ? max(1, (int)P.fringe_threshold / 2) : (int)P.fringe_threshold));
+        {
+            // the batching thresholds are fractions of the lanes that still have work: a wave in the tail of the launch
+            // (queue empty, most lanes retired) must not wait for 32 idle lanes that will never come
+            const int n_alive = __popcll(alive_mask);
+            shade_thr = max(1, (shade_thr * n_alive) >> 6);
+            fringe_thr = max(1, (fringe_thr * n_alive) >> 6);
+        }
         for (;;) {
             const unsigned long long trav_mask = __ballot(tv.node >= 0);
             if (trav_mask == 0ull) break;
@@ -455,9 +465,17 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
                 }
                 if (COUNT) { const unsigned long long now = __builtin_amdgcn_s_memtime(); t_fringe += now - t_mark; t_mark = now; }
             } else {
-                if (tv.node >= 0 && tv.node < P.n_inner) {
-                    trav_step_inner<ITERS>(tv, ns, ro, inv, my_stack, ts);
-                    if (tv.node < 0) result_ready = true;
+                // a short burst of inner steps between two scheduling decisions: the ballots / popcounts of the loop head
+                // are a sizeable part of a 50-instruction step
+#pragma unroll 1
+                for (int burst = 0; burst < 4; burst++) {
+                    if (tv.node >= 0 && tv.node < P.n_inner) {
+                        trav_step_inner<ITERS>(tv, ns, ro, inv, my_stack, ts);
+                        if (tv.node < 0) result_ready = true;
+                    }
+                    if (COUNT && burst > 0) { ts.w_iters++; ts.w_alive += (uint32_t)__popcll(alive_mask); }
+                    if (COUNT) ts.l_inner += burst > 0 ? (uint32_t)__popcll(__ballot(tv.node >= 0 && tv.node < P.n_inner)) : 0u;
+                    if (__ballot(tv.node >= 0 && tv.node < P.n_inner) == 0ull) break;
                 }
                 if (COUNT) { const unsigned long long now = __builtin_amdgcn_s_memtime(); t_inner += now - t_mark; t_mark = now; }
             }
@@ -578,7 +596,7 @@ __global__ __launch_bounds__(64) void trace_rays_kernel(const RenderParams P, co
     V3 o = mk(0, 0, 0), d = mk(0, 0, 1);
     if (active) { o = mk(rays[6 * k + 0], rays[6 * k + 1], rays[6 * k + 2]); d = mk(rays[6 * k + 3], rays[6 * k + 4], rays[6 * k + 5]); }
     TravStats ts;
-    Trav tv; tv.node = -1; tv.sp = 0; tv.c = kFltMax; tv.hit = -1;
+    Trav tv; tv.node = -1; tv.sp = 0; tv.top = -1; tv.c = kFltMax; tv.hit = -1;
     const V3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     if (active) trav_begin<false>(tv, P.tris, P.root_ref, o, d, ts);
     NodeSrc ns;
