@@ -218,6 +218,7 @@ struct Trav {
     int top;         // the newest stack entry lives in a register (valid iff sp > 0); LDS holds entries 0 .. sp-2
     float c;         // closest_so_far
     int hit;         // triangle of the closest hit or -1
+    uint32_t nf[3];  // LDS byte address of the near pair of inner record 0, per axis (see NodeSrc)
 };
 
 // Start a closest-hit query (bvh.cu:101-119).  Returns true when the query is already finished (leaf root).
@@ -279,49 +280,78 @@ __device__ __forceinline__ f4v buf_load16(buf_rsrc r, uint32_t byte_offset) {
     return as_f4v(__builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_offset, 0, 0));
 }
 
-// LDS image of the INNER records (both children internal): three planes of float4 (the 12 box floats) and one or two
-// planes of child references -- 52 B per record when all record indices fit 16 bit (56 B otherwise) instead of the 64 B
-// global record, so that a whole ~2 300-record inner tree (cfg 3) is resident and an INNER step never leaves the CU.
+// Node record, 64 B: three axis planes (lo_L, lo_R, hi_L, hi_R) for x, y, z -- the boxes of the left / right child side
+// by side, so that one packed operation serves both children -- then lref, rref (child references: >= 0 record index,
+// < 0 ~triangle) and two pad words.  The LDS image of the INNER records (both children internal) keeps the three planes
+// as separate float4 arrays plus one or two planes of child references: 52 B per record when all record indices fit
+// 16 bit (56 B otherwise), so that a whole ~2 300-record inner tree (cfg 3) is resident and an INNER step never leaves
+// the CU.
+//
+// aabb::hit swaps t0 / t1 when 1/dir is negative (aabb.cu:21-25); selecting the operands before the arithmetic is the
+// same thing.  In LDS the selection is free: the near pair of an axis is an 8-byte read at +0 (dir >= 0) or +8 inside
+// the plane entry and the far pair is the other half, so a ray keeps three byte addresses (nf) and the step issues six
+// ds_read_b64 instead of three ds_read_b128 plus a dozen v_cndmask.
 typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
+typedef __attribute__((address_space(3))) const f2 lds_cf2;
+typedef __attribute__((address_space(3))) const char lds_cchar;
 struct NodeSrc {
     buf_rsrc global_nodes;
-    lds_cf4 *lds_q0, *lds_q1, *lds_q2;
-    lds_cu32 *lds_r0, *lds_r1;      // refs16: r0 = lref | rref << 16; else r0 = lref, r1 = rref
+    lds_cf4 *lds_q0, *lds_q1, *lds_q2;   // x / y / z planes
+    lds_cu32 *lds_r0, *lds_r1;           // NARROW: r0 = lref | rref << 16; else r0 = lref, r1 = rref
     int n_cached;
-    bool refs16;
 };
-__device__ __forceinline__ void fetch_node_global(const NodeSrc &ns, int node, f4v &q0, f4v &q1, f4v &q2, int &lref, int &rref) {
+struct BoxPairs { f2 nx, fx, ny, fy, nz, fz; };   // near / far plane of each axis, .x = left child, .y = right child
+
+__device__ __forceinline__ void select_near_far(const f4v &q, bool positive, f2 &nr, f2 &fr) {
+    nr = positive ? mk2(q.x, q.y) : mk2(q.z, q.w);
+    fr = positive ? mk2(q.z, q.w) : mk2(q.x, q.y);
+}
+__device__ __forceinline__ void fetch_node_global(const NodeSrc &ns, int node, V3 inv, BoxPairs &b, int &lref, int &rref) {
     const uint32_t off = (uint32_t)node * 64u;
-    q0 = buf_load16(ns.global_nodes, off); q1 = buf_load16(ns.global_nodes, off + 16u);
-    q2 = buf_load16(ns.global_nodes, off + 32u);
-    const f4v q3 = buf_load16(ns.global_nodes, off + 48u);
+    const f4v q0 = buf_load16(ns.global_nodes, off), q1 = buf_load16(ns.global_nodes, off + 16u);
+    const f4v q2 = buf_load16(ns.global_nodes, off + 32u), q3 = buf_load16(ns.global_nodes, off + 48u);
+    select_near_far(q0, inv.x >= 0, b.nx, b.fx);
+    select_near_far(q1, inv.y >= 0, b.ny, b.fy);
+    select_near_far(q2, inv.z >= 0, b.nz, b.fz);
     lref = (int)__float_as_uint(q3.x); rref = (int)__float_as_uint(q3.y);
 }
+// LDS byte address of the near pair of record 0 on every axis, for this ray
+__device__ __forceinline__ void ray_near_addresses(const NodeSrc &ns, V3 inv, uint32_t nf[3]) {
+    nf[0] = (uint32_t)(uintptr_t)ns.lds_q0 + (inv.x >= 0 ? 0u : 8u);
+    nf[1] = (uint32_t)(uintptr_t)ns.lds_q1 + (inv.y >= 0 ? 0u : 8u);
+    nf[2] = (uint32_t)(uintptr_t)ns.lds_q2 + (inv.z >= 0 ? 0u : 8u);
+}
 // record that may be LDS resident (inner records only)
-__device__ __forceinline__ void fetch_node(const NodeSrc &ns, int node, f4v &q0, f4v &q1, f4v &q2, int &lref, int &rref) {
+template <bool NARROW>
+__device__ __forceinline__ void fetch_node(const NodeSrc &ns, int node, V3 inv, const uint32_t nf[3], BoxPairs &b, int &lref, int &rref) {
     if (node < ns.n_cached) {
-        q0 = ns.lds_q0[node]; q1 = ns.lds_q1[node]; q2 = ns.lds_q2[node];
+        const uint32_t rec = (uint32_t)node << 4;
+        const uint32_t ax = rec + nf[0], ay = rec + nf[1], az = rec + nf[2];
+        b.nx = *(lds_cf2 *)(uintptr_t)ax; b.fx = *(lds_cf2 *)(uintptr_t)(ax ^ 8u);
+        b.ny = *(lds_cf2 *)(uintptr_t)ay; b.fy = *(lds_cf2 *)(uintptr_t)(ay ^ 8u);
+        b.nz = *(lds_cf2 *)(uintptr_t)az; b.fz = *(lds_cf2 *)(uintptr_t)(az ^ 8u);
         const uint32_t r0 = ns.lds_r0[node];
-        if (ns.refs16) { lref = (int)(r0 & 0xffffu); rref = (int)(r0 >> 16); }
+        if (NARROW) { lref = (int)(r0 & 0xffffu); rref = (int)(r0 >> 16); }
         else { lref = (int)r0; rref = (int)ns.lds_r1[node]; }
     } else {
-        fetch_node_global(ns, node, q0, q1, q2, lref, rref);
+        fetch_node_global(ns, node, inv, b, lref, rref);
     }
 }
 
-// Traversal stack: this lane's column, element k at index k*64; 16-bit entries when every record index fits.
+// Traversal stack: this lane's column, element k at index k*64; 16-bit entries when every record index fits (NARROW).
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
 typedef __attribute__((address_space(3))) uint16_t lds_u16;
 struct StackRef {
-    lds_u32 *s32;      // used when !narrow
-    lds_u16 *s16;      // used when narrow
-    bool narrow;
+    lds_u32 *s32;      // used when !NARROW
+    lds_u16 *s16;      // used when NARROW
 };
+template <bool NARROW>
 __device__ __forceinline__ void stack_push(const StackRef &st, int sp, int ref) {
-    if (st.narrow) st.s16[sp * 64] = (uint16_t)ref; else st.s32[sp * 64] = (uint32_t)ref;
+    if (NARROW) st.s16[sp * 64] = (uint16_t)ref; else st.s32[sp * 64] = (uint32_t)ref;
 }
+template <bool NARROW>
 __device__ __forceinline__ int stack_pop(const StackRef &st, int sp) {
-    return st.narrow ? (int)st.s16[sp * 64] : (int)st.s32[sp * 64];
+    return NARROW ? (int)st.s16[sp * 64] : (int)st.s32[sp * 64];
 }
 
 // aabb::hit (bvh/aabb.cu:7-40) for both child boxes at once (x = left child, y = right child), packed fp32, with the
@@ -330,13 +360,10 @@ __device__ __forceinline__ int stack_pop(const StackRef &st, int sp) {
 // The reference's per-axis early-outs are equivalent to this single final test because its running min only grows
 // and its running max only shrinks; NaN t0/t1 are ignored by both forms (comparisons false / fmaxf,fminf return the
 // other operand).
-__device__ __forceinline__ void box_pair(const f4v &q0, const f4v &q1, const f4v &q2, V3 o, V3 inv, float &e_l, float &m_l,
-                                         float &e_r, float &m_r) {
-    const bool px = inv.x >= 0, py = inv.y >= 0, pz = inv.z >= 0;
-    const f2 lox = mk2(q0.x, q1.z), hix = mk2(q0.y, q1.w), loy = mk2(q0.z, q2.x), hiy = mk2(q0.w, q2.y), loz = mk2(q1.x, q2.z), hiz = mk2(q1.y, q2.w);
-    const f2 t0x = ((px ? lox : hix) - o.x) * inv.x, t1x = ((px ? hix : lox) - o.x) * inv.x;
-    const f2 t0y = ((py ? loy : hiy) - o.y) * inv.y, t1y = ((py ? hiy : loy) - o.y) * inv.y;
-    const f2 t0z = ((pz ? loz : hiz) - o.z) * inv.z, t1z = ((pz ? hiz : loz) - o.z) * inv.z;
+__device__ __forceinline__ void box_pair(const BoxPairs &b, V3 o, V3 inv, float &e_l, float &m_l, float &e_r, float &m_r) {
+    const f2 t0x = (b.nx - o.x) * inv.x, t1x = (b.fx - o.x) * inv.x;
+    const f2 t0y = (b.ny - o.y) * inv.y, t1y = (b.fy - o.y) * inv.y;
+    const f2 t0z = (b.nz - o.z) * inv.z, t1z = (b.fz - o.z) * inv.z;
     e_l = fmaxf(fmaxf(fmaxf(0.0f, t0x.x), t0y.x), t0z.x); e_r = fmaxf(fmaxf(fmaxf(0.0f, t0x.y), t0y.y), t0z.y);
     // min(c, t1x, t1y, t1z) = min(c, m) with m = min over the non-NaN t1 (fminf ignores NaNs in any order)
     m_l = fminf(fminf(t1x.x, t1y.x), t1z.x); m_r = fminf(fminf(t1x.y, t1y.y), t1z.y);
@@ -345,18 +372,19 @@ __device__ __forceinline__ void box_pair(const f4v &q0, const f4v &q1, const f4v
 // bvh.cu:154-160: pop when neither child is to be traversed; otherwise descend left first and push right iff both.
 // The newest entry is kept in a register: a pop hands it out immediately and re-fills the register with an LDS read
 // whose result is not needed before the NEXT pop or push, so the LDS latency leaves the critical path of the step.
+template <bool NARROW>
 __device__ __forceinline__ void trav_advance(Trav &tv, bool trav_l, bool trav_r, int lref, int rref, const StackRef &stack) {
     if (!trav_l && !trav_r) {
         if (tv.sp == 0) tv.node = -1;
         else {
             tv.node = tv.top;
             tv.sp--;
-            if (tv.sp > 0) tv.top = stack_pop(stack, tv.sp - 1);
+            if (tv.sp > 0) tv.top = stack_pop<NARROW>(stack, tv.sp - 1);
         }
     } else {
         tv.node = trav_l ? lref : rref;
         if (trav_l && trav_r) {
-            if (tv.sp > 0) stack_push(stack, tv.sp - 1, tv.top);
+            if (tv.sp > 0) stack_push<NARROW>(stack, tv.sp - 1, tv.top);
             tv.top = rref;
             tv.sp++;
         }
@@ -364,33 +392,33 @@ __device__ __forceinline__ void trav_advance(Trav &tv, bool trav_l, bool trav_r,
 }
 
 // Visit of an INNER record (both children internal): two box tests, no triangle work.
-template <bool COUNT>
+template <bool COUNT, bool NARROW>
 __device__ __forceinline__ void trav_step_inner(Trav &tv, const NodeSrc &ns, V3 o, V3 inv, const StackRef &stack, TravStats &ts) {
-    f4v q0, q1, q2;
+    BoxPairs b;
     int lref, rref;
-    fetch_node(ns, tv.node, q0, q1, q2, lref, rref);
+    fetch_node<NARROW>(ns, tv.node, inv, tv.nf, b, lref, rref);
     if (COUNT) { ts.n_iters++; ts.n_box += 2u; }
     float e_l, m_l, e_r, m_r;
-    box_pair(q0, q1, q2, o, inv, e_l, m_l, e_r, m_r);
+    box_pair(b, o, inv, e_l, m_l, e_r, m_r);
     const float c = tv.c;
     const bool trav_l = !(fminf(c, m_l) <= e_l);
     const bool trav_r = !(fminf(c, m_r) <= e_r);
-    trav_advance(tv, trav_l, trav_r, lref, rref, stack);
+    trav_advance<NARROW>(tv, trav_l, trav_r, lref, rref, stack);
 }
 
 // Visit of a FRINGE record (at least one leaf child).
-template <bool COUNT>
+template <bool COUNT, bool NARROW>
 __device__ __forceinline__ void trav_step_fringe(Trav &tv, const NodeSrc &ns, buf_rsrc tris, V3 o, V3 d,
                                                  V3 inv, const StackRef &stack, TravStats &ts) {
-    f4v q0, q1, q2;
+    BoxPairs b;
     int lref, rref;
-    fetch_node_global(ns, tv.node, q0, q1, q2, lref, rref);      // fringe records are never LDS resident
+    fetch_node_global(ns, tv.node, inv, b, lref, rref);      // fringe records are never LDS resident
     const bool leaf_l = lref < 0, leaf_r = rref < 0;
     if (COUNT) { ts.n_iters++; ts.n_tri += (leaf_l ? 1u : 0u) + (leaf_r ? 1u : 0u); ts.n_box += (leaf_l ? 0u : 1u) + (leaf_r ? 0u : 1u); }
 
     // ---- both child boxes; a leaf child's slot holds a box too, its result is ignored ------------------------------
     float e_l, m_l, e_r, m_r;
-    box_pair(q0, q1, q2, o, inv, e_l, m_l, e_r, m_r);
+    box_pair(b, o, inv, e_l, m_l, e_r, m_r);
 
     // ---- both leaf triangles in one segment ------------------------------------------------------------------------
     float t_l = 0.f, t_r = 0.f;
@@ -430,7 +458,7 @@ __device__ __forceinline__ void trav_step_fringe(Trav &tv, const NodeSrc &ns, bu
     if (leaf_r) { trav_r = false; if (ok_r && t_r <= c) { c = t_r; tv.hit = ~rref; } }
     else trav_r = !(fminf(c, m_r) <= e_r);
     tv.c = c;
-    trav_advance(tv, trav_l, trav_r, lref, rref, stack);
+    trav_advance<NARROW>(tv, trav_l, trav_r, lref, rref, stack);
 }
 
 }  // namespace srt

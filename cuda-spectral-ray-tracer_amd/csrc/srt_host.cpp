@@ -347,8 +347,10 @@ int flatten_scene(const srt_scene &s, FlatScene &out) {
         const BvhNode &nd = s.nodes[pre[r]];
         const BvhNode &l = s.nodes[nd.left], &rr = s.nodes[nd.right];
         float *o = &out.nodes[16 * r];
-        memcpy(o, l.box, 6 * sizeof(float));
-        memcpy(o + 6, rr.box, 6 * sizeof(float));
+        for (int a = 0; a < 3; a++) {   // axis plane: (lo_L, lo_R, hi_L, hi_R), see NodeSrc in srt_device.h
+            o[4 * a + 0] = l.box[2 * a]; o[4 * a + 1] = rr.box[2 * a];
+            o[4 * a + 2] = l.box[2 * a + 1]; o[4 * a + 3] = rr.box[2 * a + 1];
+        }
         o[12] = bits_to_float((uint32_t)child_ref(nd.left));
         o[13] = bits_to_float((uint32_t)child_ref(nd.right));
     }

@@ -104,7 +104,7 @@ __global__ void init_rng_kernel(uint32_t *rng, uint32_t n_lanes, uint64_t seed) 
 // renders a pixel has no influence on the result (the RNG stream belongs to the pixel).
 // MODE 0: production; MODE 1: instrumented (counts V / T / utilisation); MODE 2: cost probe -- renders P.spp samples per
 // pixel from a COPY of the RNG state, writes nothing but the per-tile traversal cost used to order the pixel queue.
-template <int MODE>
+template <int MODE, bool NARROW>
 __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
     constexpr bool COUNT = (MODE == 1);
     constexpr bool PROBE = (MODE == 2);
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
     lds_uniforms *U = (lds_uniforms *)lds4;
     float4 *s_cmf = lds4 + kLdsUniF4;
     float2 *s_bg = reinterpret_cast<float2 *>(lds4 + kLdsUniF4 + kLdsCmfF4);
-    const bool narrow = P.n_records <= 65535;
+    constexpr bool narrow = NARROW;           // P.n_records <= 65535 (launcher): 16-bit child references and stack entries
     const uint32_t nc = (uint32_t)P.n_cached;
     float4 *s_q0 = lds4 + kLdsTablesF4, *s_q1 = s_q0 + nc, *s_q2 = s_q1 + nc;
     uint32_t *s_r0 = reinterpret_cast<uint32_t *>(s_q2 + nc), *s_r1 = s_r0 + nc;
@@ -151,14 +151,13 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
     ns.global_nodes = make_rsrc(P.nodes, (uint32_t)P.n_records * 64u);
     ns.lds_q0 = (lds_cf4 *)s_q0; ns.lds_q1 = (lds_cf4 *)s_q1; ns.lds_q2 = (lds_cf4 *)s_q2;
     ns.lds_r0 = (lds_cu32 *)s_r0; ns.lds_r1 = (lds_cu32 *)s_r1;
-    ns.n_cached = P.n_cached; ns.refs16 = narrow;
+    ns.n_cached = P.n_cached;
     const buf_rsrc tri_rsrc = make_rsrc(P.tris, P.n_tris * 48u);
     const uint32_t n_local_pixels = P.tiles_local * 64u;
     const uint32_t spp = P.spp;
     StackRef my_stack;
     {
         const size_t depth = (size_t)(P.stack_depth < 1 ? 1 : P.stack_depth);
-        my_stack.narrow = narrow;
         my_stack.s16 = (lds_u16 *)(s_stack_base + (size_t)wave * depth * 128u) + lane;
         my_stack.s32 = (lds_u32 *)(s_stack_base + (size_t)wave * depth * 256u) + lane;
     }
@@ -176,7 +175,7 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
     float pw[kWavelengths];
 #pragma unroll
     for (int k = 0; k < kWavelengths; k++) pw[k] = 0.f;
-    Trav tv; tv.node = -1; tv.sp = 0; tv.top = -1; tv.c = kFltMax; tv.hit = -1;
+    Trav tv; tv.node = -1; tv.sp = 0; tv.top = -1; tv.c = kFltMax; tv.hit = -1; tv.nf[0] = tv.nf[1] = tv.nf[2] = 0u;
     uint32_t n_rays = 0;
     TravStats ts;
     // latency mode (see the traversal phase): cost class of this lane's pixel, from the probe
@@ -417,6 +416,7 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
             if (begin_trav) {
                 n_rays++;
                 inv = mk(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);           // aabb.cu:17, hoisted out of the box test
+                ray_near_addresses(ns, inv, tv.nf);
                 if (trav_begin<ITERS>(tv, P.tris, P.root_ref, ro, rd, ts)) result_ready = true;
             }
         }
@@ -460,7 +460,7 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
             if (COUNT) { ts.w_iters++; ts.w_alive += (uint32_t)__popcll(alive_mask); if (do_fringe) { ts.w_fringe++; ts.l_fringe += (uint32_t)__popcll(fringe_mask); } else ts.l_inner += (uint32_t)__popcll(trav_mask & ~fringe_mask); }
             if (do_fringe) {
                 if (tv.node >= P.n_inner) {
-                    trav_step_fringe<ITERS>(tv, ns, tri_rsrc, ro, rd, inv, my_stack, ts);
+                    trav_step_fringe<ITERS, NARROW>(tv, ns, tri_rsrc, ro, rd, inv, my_stack, ts);
                     if (tv.node < 0) result_ready = true;
                 }
                 if (COUNT) { const unsigned long long now = __builtin_amdgcn_s_memtime(); t_fringe += now - t_mark; t_mark = now; }
@@ -470,7 +470,7 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
 #pragma unroll 1
                 for (int burst = 0; burst < 4; burst++) {
                     if (tv.node >= 0 && tv.node < P.n_inner) {
-                        trav_step_inner<ITERS>(tv, ns, ro, inv, my_stack, ts);
+                        trav_step_inner<ITERS, NARROW>(tv, ns, ro, inv, my_stack, ts);
                         if (tv.node < 0) result_ready = true;
                     }
                     if (COUNT && burst > 0) { ts.w_iters++; ts.w_alive += (uint32_t)__popcll(alive_mask); }
@@ -596,16 +596,16 @@ __global__ __launch_bounds__(64) void trace_rays_kernel(const RenderParams P, co
     V3 o = mk(0, 0, 0), d = mk(0, 0, 1);
     if (active) { o = mk(rays[6 * k + 0], rays[6 * k + 1], rays[6 * k + 2]); d = mk(rays[6 * k + 3], rays[6 * k + 4], rays[6 * k + 5]); }
     TravStats ts;
-    Trav tv; tv.node = -1; tv.sp = 0; tv.top = -1; tv.c = kFltMax; tv.hit = -1;
+    Trav tv; tv.node = -1; tv.sp = 0; tv.top = -1; tv.c = kFltMax; tv.hit = -1; tv.nf[0] = tv.nf[1] = tv.nf[2] = 0u;
     const V3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     if (active) trav_begin<false>(tv, P.tris, P.root_ref, o, d, ts);
     NodeSrc ns;
     ns.global_nodes = make_rsrc(P.nodes, (uint32_t)P.n_records * 64u);
-    ns.lds_q0 = ns.lds_q1 = ns.lds_q2 = nullptr; ns.lds_r0 = ns.lds_r1 = nullptr; ns.n_cached = 0; ns.refs16 = false;
+    ns.lds_q0 = ns.lds_q1 = ns.lds_q2 = nullptr; ns.lds_r0 = ns.lds_r1 = nullptr; ns.n_cached = 0;
     const buf_rsrc tri_rsrc = make_rsrc(P.tris, P.n_tris * 48u);
-    StackRef my_stack; my_stack.narrow = false; my_stack.s16 = nullptr; my_stack.s32 = (lds_u32 *)s_stack + lane;
+    StackRef my_stack; my_stack.s16 = nullptr; my_stack.s32 = (lds_u32 *)s_stack + lane;
     while (__ballot(tv.node >= 0) != 0ull) {
-        if (tv.node >= 0) trav_step_fringe<false>(tv, ns, tri_rsrc, o, d, inv, my_stack, ts);   // handles inner records too
+        if (tv.node >= 0) trav_step_fringe<false, false>(tv, ns, tri_rsrc, o, d, inv, my_stack, ts);   // handles inner records too
     }
     const float t = tv.c;
     const int tri = tv.hit;
@@ -662,7 +662,7 @@ hipError_t launch_init_rng(uint32_t *rng, uint32_t n_lanes, uint64_t seed, hipSt
     return hipGetLastError();
 }
 
-template <int MODE>
+template <int MODE, bool NARROW>
 static hipError_t launch_render_mode(const RenderParams &p_in, uint32_t n_cu, hipStream_t st) {
     RenderParams p = p_in;
     int wpb = 1, n_cached = 0;
@@ -672,25 +672,26 @@ static hipError_t launch_render_mode(const RenderParams &p_in, uint32_t n_cu, hi
     }
     p.n_cached = n_cached;
     const size_t lds = render_lds_bytes(p.stack_depth, wpb, n_cached, p.n_records);
-    static bool attr_set[3] = {false, false, false};
-    if (!attr_set[MODE]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget);
-        attr_set[MODE] = true;
+    static bool attr_set = false;   // one flag per template instance
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<MODE, NARROW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget);
+        attr_set = true;
     }
     // persistent waves: fill every CU (16 waves per CU at this kernel's register budget), never more waves than tiles
     uint32_t waves_per_cu = p.waves_per_cu_override > 0 ? p.waves_per_cu_override : 16u;
     uint32_t n_waves = n_cu * waves_per_cu;
     if (n_waves > p.tiles_local) n_waves = p.tiles_local;
     const uint32_t n_blocks = (n_waves + (uint32_t)wpb - 1) / (uint32_t)wpb;
-    hipLaunchKernelGGL(render_kernel<MODE>, dim3(n_blocks), dim3(64 * wpb), lds, st, p);
+    hipLaunchKernelGGL((render_kernel<MODE, NARROW>), dim3(n_blocks), dim3(64 * wpb), lds, st, p);
     return hipGetLastError();
 }
 
 hipError_t launch_render(const RenderParams &p, uint32_t n_cu, int mode, hipStream_t st) {
     if (p.tiles_local == 0) return hipSuccess;
-    if (mode == 1) return launch_render_mode<1>(p, n_cu, st);
-    if (mode == 2) return launch_render_mode<2>(p, n_cu, st);
-    return launch_render_mode<0>(p, n_cu, st);
+    const bool narrow = narrow_refs(p.n_records);
+    if (mode == 1) return narrow ? launch_render_mode<1, true>(p, n_cu, st) : launch_render_mode<1, false>(p, n_cu, st);
+    if (mode == 2) return narrow ? launch_render_mode<2, true>(p, n_cu, st) : launch_render_mode<2, false>(p, n_cu, st);
+    return narrow ? launch_render_mode<0, true>(p, n_cu, st) : launch_render_mode<0, false>(p, n_cu, st);
 }
 
 hipError_t launch_order_tiles(const uint32_t *cost, uint32_t *order, uint32_t n, uint32_t *sched, hipStream_t st) {
