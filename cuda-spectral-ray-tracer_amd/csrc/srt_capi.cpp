@@ -17,7 +17,7 @@ struct srt_ctx {
     int device = 0;
     std::string err;
     // scene images in HBM
-    float *d_nodes = nullptr, *d_tris = nullptr, *d_mat_sd = nullptr, *d_mat_par = nullptr, *d_bg = nullptr, *d_cmf = nullptr;
+    float *d_nodes = nullptr, *d_fringe = nullptr, *d_tris = nullptr, *d_mat_sd = nullptr, *d_mat_par = nullptr, *d_bg = nullptr, *d_cmf = nullptr;
     int root_ref = 0, stack_depth = 1, n_inner = 0, n_records = 0;
     uint32_t n_tris = 0;
     uint32_t n_materials = 0;
@@ -38,8 +38,8 @@ struct srt_ctx {
     size_t tiles_capacity = 0;      // floats
     unsigned long long *d_counters = nullptr;     // [kCounters] statistics + 1 word pixel-queue head behind them
     int n_cu = 256;
-    uint32_t fringe_threshold = 20;                    // env SRT_FRINGE_THRESHOLD
-    uint32_t shade_threshold = 32, waves_per_cu = 0;   // tuning knobs (env SRT_SHADE_THRESHOLD / SRT_WAVES_PER_CU)
+    uint32_t fringe_threshold = 16;                    // env SRT_FRINGE_THRESHOLD
+    uint32_t shade_threshold = 40, waves_per_cu = 0;   // tuning knobs (env SRT_SHADE_THRESHOLD / SRT_WAVES_PER_CU)
     uint32_t debug_lane_limit = 0;                     // env SRT_DEBUG_LANE_LIMIT (experiments: partial tiles)
     bool latency_mode = false;                          // experimental (env SRT_LATENCY_MODE=1): wave priorities / threshold scaling by tile cost class
     uint32_t probe_spp = 2;                            // samples of the cost probe (env SRT_PROBE_SPP, 0 = no ordering)
@@ -78,7 +78,7 @@ int upload(srt_ctx *ctx, T **dst, const std::vector<float> &src) {
 
 void fill_params(const srt_ctx *c, RenderParams &p) {
     memset(&p, 0, sizeof(p));
-    p.nodes = (const float4 *)c->d_nodes; p.tris = (const float4 *)c->d_tris;
+    p.nodes = (const float4 *)c->d_nodes; p.fringe = (const float4 *)c->d_fringe; p.tris = (const float4 *)c->d_tris;
     p.mat_sd = (const float2 *)c->d_mat_sd; p.mat_par = (const float4 *)c->d_mat_par;
     p.bg_sd = (const float2 *)c->d_bg; p.cmf = (const float4 *)c->d_cmf;
     p.root_ref = c->root_ref; p.stack_depth = c->stack_depth; p.n_materials = c->n_materials;
@@ -142,7 +142,7 @@ void srt_destroy(srt_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    void *bufs[] = {c->d_nodes, c->d_tris, c->d_mat_sd, c->d_mat_par, c->d_bg, c->d_cmf, c->d_rng, c->d_fb, c->d_tiles, c->d_counters, c->d_tile_cost, c->d_tile_order};
+    void *bufs[] = {c->d_nodes, c->d_fringe, c->d_tris, c->d_mat_sd, c->d_mat_par, c->d_bg, c->d_cmf, c->d_rng, c->d_fb, c->d_tiles, c->d_counters, c->d_tile_cost, c->d_tile_order};
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -159,6 +159,7 @@ int srt_upload_scene(srt_ctx *c, const srt_scene *s) {
     if (rc != SRT_OK) return fail(c, rc, global_error());
     if (render_lds_bytes(f.stack_depth, 1, 0, f.n_records) > 64 * 1024) return fail(c, SRT_ERR_BVH, "srt_upload_scene: BVH too deep for the LDS traversal stack");
     if ((rc = upload(c, &c->d_nodes, f.nodes)) != SRT_OK) return rc;
+    if ((rc = upload(c, &c->d_fringe, f.fringe)) != SRT_OK) return rc;
     if ((rc = upload(c, &c->d_tris, f.tris)) != SRT_OK) return rc;
     if ((rc = upload(c, &c->d_mat_sd, f.mat_sd)) != SRT_OK) return rc;
     if ((rc = upload(c, &c->d_mat_par, f.mat_par)) != SRT_OK) return rc;

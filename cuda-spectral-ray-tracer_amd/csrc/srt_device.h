@@ -295,7 +295,9 @@ typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
 typedef __attribute__((address_space(3))) const f2 lds_cf2;
 typedef __attribute__((address_space(3))) const char lds_cchar;
 struct NodeSrc {
-    buf_rsrc global_nodes;
+    buf_rsrc global_nodes;               // INNER records, 64 B each
+    buf_rsrc global_fringe;              // FRINGE records, 128 B each, indexed by record - n_inner
+    int n_inner;
     lds_cf4 *lds_q0, *lds_q1, *lds_q2;   // x / y / z planes
     lds_cu32 *lds_r0, *lds_r1;           // NARROW: r0 = lref | rref << 16; else r0 = lref, r1 = rref
     int n_cached;
@@ -408,27 +410,32 @@ __device__ __forceinline__ void trav_step_inner(Trav &tv, const NodeSrc &ns, V3 
 
 // Visit of a FRINGE record (at least one leaf child).
 template <bool COUNT, bool NARROW>
-__device__ __forceinline__ void trav_step_fringe(Trav &tv, const NodeSrc &ns, buf_rsrc tris, V3 o, V3 d,
+__device__ __forceinline__ void trav_step_fringe(Trav &tv, const NodeSrc &ns, V3 o, V3 d,
                                                  V3 inv, const StackRef &stack, TravStats &ts) {
-    BoxPairs b;
-    int lref, rref;
-    fetch_node_global(ns, tv.node, inv, b, lref, rref);      // fringe records are never LDS resident
+    // one round of independent loads: header + a 48-byte block per child (box or triangle, see flatten_scene)
+    const uint32_t off = (uint32_t)(tv.node - ns.n_inner) * 128u;
+    const f4v hd = buf_load16(ns.global_fringe, off);
+    const f4v al = buf_load16(ns.global_fringe, off + 16u), bl = buf_load16(ns.global_fringe, off + 32u), cl = buf_load16(ns.global_fringe, off + 48u);
+    const f4v ar = buf_load16(ns.global_fringe, off + 64u), br = buf_load16(ns.global_fringe, off + 80u), cr = buf_load16(ns.global_fringe, off + 96u);
+    const int lref = (int)__float_as_uint(hd.x), rref = (int)__float_as_uint(hd.y);
     const bool leaf_l = lref < 0, leaf_r = rref < 0;
     if (COUNT) { ts.n_iters++; ts.n_tri += (leaf_l ? 1u : 0u) + (leaf_r ? 1u : 0u); ts.n_box += (leaf_l ? 0u : 1u) + (leaf_r ? 0u : 1u); }
 
-    // ---- both child boxes; a leaf child's slot holds a box too, its result is ignored ------------------------------
+    // ---- both child boxes; a leaf child's block holds a triangle, its box result is ignored --------------------------
     float e_l, m_l, e_r, m_r;
-    box_pair(b, o, inv, e_l, m_l, e_r, m_r);
+    {
+        const bool px = inv.x >= 0, py = inv.y >= 0, pz = inv.z >= 0;
+        BoxPairs b;
+        b.nx = mk2(px ? al.x : al.y, px ? ar.x : ar.y); b.fx = mk2(px ? al.y : al.x, px ? ar.y : ar.x);
+        b.ny = mk2(py ? al.z : al.w, py ? ar.z : ar.w); b.fy = mk2(py ? al.w : al.z, py ? ar.w : ar.z);
+        b.nz = mk2(pz ? bl.x : bl.y, pz ? br.x : br.y); b.fz = mk2(pz ? bl.y : bl.x, pz ? br.y : br.x);
+        box_pair(b, o, inv, e_l, m_l, e_r, m_r);
+    }
 
     // ---- both leaf triangles in one segment ------------------------------------------------------------------------
     float t_l = 0.f, t_r = 0.f;
     bool ok_l = false, ok_r = false;          // plane not parallel, t >= tmin, inside (everything but `t <= c`)
     if (leaf_l || leaf_r) {
-        const int il = leaf_l ? ~lref : 0, ir = leaf_r ? ~rref : 0;
-        const uint32_t ol = (uint32_t)il * 48u, orr = (uint32_t)ir * 48u;
-        const f4v al = buf_load16(tris, ol), ar = buf_load16(tris, orr);
-        const f4v bl = buf_load16(tris, ol + 16u), br = buf_load16(tris, orr + 16u);
-        const f4v cl = buf_load16(tris, ol + 32u), cr = buf_load16(tris, orr + 32u);
         const f2 nx = mk2(al.x, ar.x), ny = mk2(al.y, ar.y), nz = mk2(al.z, ar.z), D = mk2(al.w, ar.w);
         const f2 denom = nx * d.x + ny * d.y + nz * d.z;                      // dot(normal, dir), tri.cu:9
         const f2 num = D - (nx * o.x + ny * o.y + nz * o.z);                  // D - dot(normal, origin), tri.cu:17

@@ -342,17 +342,35 @@ int flatten_scene(const srt_scene &s, FlatScene &out) {
         }
     }
     auto child_ref = [&](int32_t k) -> int32_t { return s.nodes[k].prim >= 0 ? ~s.nodes[k].prim : rec_index[k]; };
-    out.nodes.assign(16 * std::max<size_t>(pre.size(), 1), 0.f);
+    // INNER records, 64 B: three axis planes (lo_L, lo_R, hi_L, hi_R), then lref, rref (see NodeSrc in srt_device.h).
+    // FRINGE records, 128 B: lref, rref, two pad words, then one 48-byte block per child -- the child's box
+    // (xmin xmax ymin ymax | zmin zmax 0 0 | 0 0 0 0) when it is internal, a copy of its triangle record when it is a leaf --
+    // so that a fringe visit is ONE round of independent loads instead of record -> triangle.
+    const size_t n_in = (size_t)out.n_inner, n_fr = pre.size() - n_in;
+    out.nodes.assign(16 * std::max<size_t>(n_in, 1), 0.f);
+    out.fringe.assign(32 * std::max<size_t>(n_fr, 1), 0.f);
     for (size_t r = 0; r < pre.size(); r++) {
         const BvhNode &nd = s.nodes[pre[r]];
         const BvhNode &l = s.nodes[nd.left], &rr = s.nodes[nd.right];
-        float *o = &out.nodes[16 * r];
-        for (int a = 0; a < 3; a++) {   // axis plane: (lo_L, lo_R, hi_L, hi_R), see NodeSrc in srt_device.h
-            o[4 * a + 0] = l.box[2 * a]; o[4 * a + 1] = rr.box[2 * a];
-            o[4 * a + 2] = l.box[2 * a + 1]; o[4 * a + 3] = rr.box[2 * a + 1];
+        if (r < n_in) {
+            float *o = &out.nodes[16 * r];
+            for (int a = 0; a < 3; a++) {
+                o[4 * a + 0] = l.box[2 * a]; o[4 * a + 1] = rr.box[2 * a];
+                o[4 * a + 2] = l.box[2 * a + 1]; o[4 * a + 3] = rr.box[2 * a + 1];
+            }
+            o[12] = bits_to_float((uint32_t)child_ref(nd.left));
+            o[13] = bits_to_float((uint32_t)child_ref(nd.right));
+        } else {
+            float *o = &out.fringe[32 * (r - n_in)];
+            o[0] = bits_to_float((uint32_t)child_ref(nd.left));
+            o[1] = bits_to_float((uint32_t)child_ref(nd.right));
+            const BvhNode *ch[2] = {&l, &rr};
+            for (int k = 0; k < 2; k++) {
+                float *b = o + 4 + 12 * k;
+                if (ch[k]->prim >= 0) memcpy(b, &out.tris[12 * (size_t)ch[k]->prim], 12 * sizeof(float));
+                else memcpy(b, ch[k]->box, 6 * sizeof(float));
+            }
         }
-        o[12] = bits_to_float((uint32_t)child_ref(nd.left));
-        o[13] = bits_to_float((uint32_t)child_ref(nd.right));
     }
     out.root_ref = child_ref(s.root);
     out.n_records = (int)pre.size();

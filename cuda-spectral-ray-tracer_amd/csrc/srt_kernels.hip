@@ -148,11 +148,12 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
     __syncthreads();      // the only barrier: from here on every wave runs its own state machine
 
     NodeSrc ns;
-    ns.global_nodes = make_rsrc(P.nodes, (uint32_t)P.n_records * 64u);
+    ns.global_nodes = make_rsrc(P.nodes, (uint32_t)P.n_inner * 64u);
+    ns.global_fringe = make_rsrc(P.fringe, (uint32_t)(P.n_records - P.n_inner) * 128u);
+    ns.n_inner = P.n_inner;
     ns.lds_q0 = (lds_cf4 *)s_q0; ns.lds_q1 = (lds_cf4 *)s_q1; ns.lds_q2 = (lds_cf4 *)s_q2;
     ns.lds_r0 = (lds_cu32 *)s_r0; ns.lds_r1 = (lds_cu32 *)s_r1;
     ns.n_cached = P.n_cached;
-    const buf_rsrc tri_rsrc = make_rsrc(P.tris, P.n_tris * 48u);
     const uint32_t n_local_pixels = P.tiles_local * 64u;
     const uint32_t spp = P.spp;
     StackRef my_stack;
@@ -460,7 +461,7 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
             if (COUNT) { ts.w_iters++; ts.w_alive += (uint32_t)__popcll(alive_mask); if (do_fringe) { ts.w_fringe++; ts.l_fringe += (uint32_t)__popcll(fringe_mask); } else ts.l_inner += (uint32_t)__popcll(trav_mask & ~fringe_mask); }
             if (do_fringe) {
                 if (tv.node >= P.n_inner) {
-                    trav_step_fringe<ITERS, NARROW>(tv, ns, tri_rsrc, ro, rd, inv, my_stack, ts);
+                    trav_step_fringe<ITERS, NARROW>(tv, ns, ro, rd, inv, my_stack, ts);
                     if (tv.node < 0) result_ready = true;
                 }
                 if (COUNT) { const unsigned long long now = __builtin_amdgcn_s_memtime(); t_fringe += now - t_mark; t_mark = now; }
@@ -600,12 +601,14 @@ __global__ __launch_bounds__(64) void trace_rays_kernel(const RenderParams P, co
     const V3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     if (active) trav_begin<false>(tv, P.tris, P.root_ref, o, d, ts);
     NodeSrc ns;
-    ns.global_nodes = make_rsrc(P.nodes, (uint32_t)P.n_records * 64u);
+    ns.global_nodes = make_rsrc(P.nodes, (uint32_t)P.n_inner * 64u);
+    ns.global_fringe = make_rsrc(P.fringe, (uint32_t)(P.n_records - P.n_inner) * 128u);
+    ns.n_inner = P.n_inner;
     ns.lds_q0 = ns.lds_q1 = ns.lds_q2 = nullptr; ns.lds_r0 = ns.lds_r1 = nullptr; ns.n_cached = 0;
-    const buf_rsrc tri_rsrc = make_rsrc(P.tris, P.n_tris * 48u);
     StackRef my_stack; my_stack.s16 = nullptr; my_stack.s32 = (lds_u32 *)s_stack + lane;
     while (__ballot(tv.node >= 0) != 0ull) {
-        if (tv.node >= 0) trav_step_fringe<false, false>(tv, ns, tri_rsrc, o, d, inv, my_stack, ts);   // handles inner records too
+        if (tv.node >= P.n_inner) trav_step_fringe<false, false>(tv, ns, o, d, inv, my_stack, ts);
+        else if (tv.node >= 0) trav_step_inner<false, false>(tv, ns, o, inv, my_stack, ts);   // n_cached = 0: global records
     }
     const float t = tv.c;
     const int tri = tv.hit;
