@@ -133,7 +133,10 @@ def main():
     local_tiles = None      # torch-owned staging tensor for the gather (multi-rank only)
 
     def step():
+        # one step = one complete frame: seed the per-pixel RNG streams (init_device_params, rendering.cu:320-335), render,
+        # assemble the framebuffer on rank 0.  Every step therefore produces the same image (fb_checksum).
         nonlocal local_tiles
+        r.init_device_params(W, H, args.spp, args.depth, 1984)
         r.render_chunk(W, H, 0, 0, stream)
         if world == 1:
             r.scatter_tiles(None, stream)

@@ -45,6 +45,7 @@ struct srt_ctx {
     uint32_t probe_spp = 2;                            // samples of the cost probe (env SRT_PROBE_SPP, 0 = no ordering)
     uint32_t *d_tile_cost = nullptr, *d_tile_order = nullptr;
     size_t tile_sched_capacity = 0;
+    uint64_t lanes_allocated = 0;                       // size of d_rng / d_fb in lanes
     float last_probe_ms = 0.f;
     bool count_traversal = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -188,10 +189,14 @@ int srt_init_device_params(srt_ctx *c, uint32_t tx, uint32_t ty, uint32_t bx, ui
     c->tx = tx; c->ty = ty; c->bx = bx; c->by = by; c->chunk_w = chunk_w; c->chunk_h = chunk_h;
     c->spp = (uint16_t)spp; c->bounce = (uint16_t)bounce_limit;     // short_uint, rendering.cu:154 (Q17)
     c->seed = seed; c->n_lanes = (uint32_t)lanes;
-    if (c->d_rng) { (void)hipFree(c->d_rng); c->d_rng = nullptr; }
-    if (c->d_fb) { (void)hipFree(c->d_fb); c->d_fb = nullptr; }
-    HIP_TRY(c, hipMalloc((void **)&c->d_rng, 6 * lanes * sizeof(uint32_t)));
-    HIP_TRY(c, hipMalloc((void **)&c->d_fb, kTilePlanes * lanes * sizeof(float)));
+    if (lanes != c->lanes_allocated) {   // a new frame of the same grid re-seeds in place
+        if (c->d_rng) { (void)hipFree(c->d_rng); c->d_rng = nullptr; }
+        if (c->d_fb) { (void)hipFree(c->d_fb); c->d_fb = nullptr; }
+        c->lanes_allocated = 0;
+        HIP_TRY(c, hipMalloc((void **)&c->d_rng, 6 * lanes * sizeof(uint32_t)));
+        HIP_TRY(c, hipMalloc((void **)&c->d_fb, kTilePlanes * lanes * sizeof(float)));
+        c->lanes_allocated = lanes;
+    }
     HIP_TRY(c, hipMemset(c->d_fb, 0, kTilePlanes * lanes * sizeof(float)));
     HIP_TRY(c, launch_init_rng(c->d_rng, c->n_lanes, seed, nullptr));   // init_random_states, rendering.cu:330
     HIP_TRY(c, hipDeviceSynchronize());

@@ -17,7 +17,7 @@ out = sys.argv[1]
 tot = collections.defaultdict(float); n = collections.defaultdict(int)
 for f in glob.glob(out + "/pass*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
-        if "render_kernel<0>" in row["Kernel_Name"]:
+        if "render_kernel<0" in row["Kernel_Name"]:
             tot[row["Counter_Name"]] += float(row["Counter_Value"]); n[row["Counter_Name"]] += 1
 with open(out + "/summary.txt", "w") as fh:
     for k in sorted(tot):

@@ -6,10 +6,10 @@ TAG=${1:-vX}
 OUT="$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p "$OUT"
-timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err" || { echo "trace run failed"; tail -5 "$OUT/bench.err"; exit 1; }
-cat "$OUT/bench.json"
-find "$OUT/trace" -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats.csv" \;
-cat "$OUT/kernel_stats.csv"
+[ "${2:-}" = "pmc-only" ] || timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err" || { echo "trace run failed"; tail -5 "$OUT/bench.err"; exit 1; }
+[ "${2:-}" = "pmc-only" ] || cat "$OUT/bench.json"
+[ "${2:-}" = "pmc-only" ] || find "$OUT/trace" -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats.csv" \;
+[ "${2:-}" = "pmc-only" ] || cat "$OUT/kernel_stats.csv"
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/pmc_$C" -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline > "$OUT/pmc_$C.json" 2> "$OUT/pmc_$C.err" || { echo "pmc $C failed"; exit 1; }
 done
@@ -19,7 +19,7 @@ out = sys.argv[1]
 res = {}
 for f in glob.glob(out + "/pmc_*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
-        if "render_kernel<0>" in row["Kernel_Name"]:
+        if "render_kernel<0" in row["Kernel_Name"]:
             res.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
 json.dump({k: v for k, v in res.items()}, open(out + "/pmc_render_kernel0.json", "w"), indent=1)
 print(json.dumps(res))
