@@ -41,7 +41,7 @@ struct srt_ctx {
     uint32_t fringe_threshold = 16;                    // env SRT_FRINGE_THRESHOLD
     uint32_t shade_threshold = 40, waves_per_cu = 0;   // tuning knobs (env SRT_SHADE_THRESHOLD / SRT_WAVES_PER_CU)
     uint32_t debug_lane_limit = 0;                     // env SRT_DEBUG_LANE_LIMIT (experiments: partial tiles)
-    bool latency_mode = false;                          // experimental (env SRT_LATENCY_MODE=1): wave priorities / threshold scaling by tile cost class
+    uint32_t split_load_pct = 220;                    // env SRT_SPLIT_LOAD: load factor (%) of the capacity constraint in order_tiles_kernel's split policy (0 = never split)
     uint32_t probe_spp = 2;                            // samples of the cost probe (env SRT_PROBE_SPP, 0 = no ordering)
     uint32_t *d_tile_cost = nullptr, *d_tile_order = nullptr;
     size_t tile_sched_capacity = 0;
@@ -118,7 +118,7 @@ int srt_create(int device, srt_ctx **out) {
     if (const char *ev = getenv("SRT_WAVES_PER_CU")) c->waves_per_cu = (uint32_t)std::max(0, atoi(ev));
     if (const char *ev = getenv("SRT_PROBE_SPP")) c->probe_spp = (uint32_t)std::max(0, atoi(ev));
     if (const char *ev = getenv("SRT_DEBUG_LANE_LIMIT")) c->debug_lane_limit = (uint32_t)std::max(0, atoi(ev));
-    if (const char *ev = getenv("SRT_LATENCY_MODE")) c->latency_mode = atoi(ev) != 0;
+    if (const char *ev = getenv("SRT_SPLIT_LOAD")) c->split_load_pct = (uint32_t)std::max(0, atoi(ev));
     if (const char *ev = getenv("SRT_FRINGE_THRESHOLD")) c->fringe_threshold = (uint32_t)std::max(1, atoi(ev));
     {
         hipDeviceProp_t prop;
@@ -245,25 +245,30 @@ int srt_render_chunk(srt_ctx *c, uint32_t width, uint32_t height, uint32_t offx,
     // ---- cost-ordered pixel queue --------------------------------------------------------------------------------
     // A pixel is one sequential RNG stream, so the launch cannot finish before its most expensive pixel does.  A short
     // probe (probe_spp samples per pixel from a copy of the RNG state, nothing written) measures the traversal cost of
-    // every tile; the queue then hands tiles out in descending cost order (longest-processing-time-first).
-    p.tile_order = nullptr; p.tile_cost = nullptr; p.sched = nullptr; p.debug_lane_limit = c->debug_lane_limit;
+    // every tile; order_tiles_kernel then builds the queue on the device: tiles in descending cost order
+    // (longest-processing-time-first), the most expensive ones split over several waves when the launch is chain-bound.
+    p.tile_order = nullptr; p.tile_cost = nullptr; p.queue_rows = nullptr; p.queue_rows_bound = c->tiles_local;
+    p.debug_lane_limit = c->debug_lane_limit;
     const bool ordered = c->probe_spp > 0 && c->spp > 4 * c->probe_spp && c->tiles_local > 1;
     if (ordered) {
         if (c->tiles_local > c->tile_sched_capacity) {
             if (c->d_tile_cost) { (void)hipFree(c->d_tile_cost); c->d_tile_cost = nullptr; }
             if (c->d_tile_order) { (void)hipFree(c->d_tile_order); c->d_tile_order = nullptr; }
             HIP_TRY(c, hipMalloc((void **)&c->d_tile_cost, c->tiles_local * sizeof(uint32_t)));
-            HIP_TRY(c, hipMalloc((void **)&c->d_tile_order, (c->tiles_local + 4) * sizeof(uint32_t)));   // + 3 class boundaries
+            // [rows: up to 64 per tile][sorted tile ids][queue_info]
+            HIP_TRY(c, hipMalloc((void **)&c->d_tile_order, ((size_t)c->tiles_local * 65 + 4) * sizeof(uint32_t)));
             c->tile_sched_capacity = c->tiles_local;
         }
+        uint32_t *rows = c->d_tile_order, *sorted = rows + (size_t)c->tile_sched_capacity * 64, *queue_info = sorted + c->tile_sched_capacity;
         HIP_TRY(c, hipMemsetAsync(c->d_tile_cost, 0, c->tiles_local * sizeof(uint32_t), st));
         RenderParams pp = p;
         pp.spp = c->probe_spp; pp.tile_cost = c->d_tile_cost;
         HIP_TRY(c, launch_render(pp, (uint32_t)c->n_cu, 2, st));
-        HIP_TRY(c, launch_order_tiles(c->d_tile_cost, c->d_tile_order, c->tiles_local, c->d_tile_order + c->tiles_local, st));   // device-side, no host sync
+        HIP_TRY(c, launch_order_tiles(c->d_tile_cost, sorted, rows, c->tiles_local, (uint32_t)c->n_cu * 16u, c->split_load_pct, queue_info, st));   // device-side, no host sync
         HIP_TRY(c, hipMemsetAsync(c->d_counters + kCounters, 0, sizeof(unsigned long long), st));   // rewind the queue head
-        p.tile_order = c->d_tile_order;
-        if (c->latency_mode) p.sched = c->d_tile_order + c->tiles_local;
+        p.tile_order = rows;
+        p.queue_rows = queue_info;
+        if (c->split_load_pct) p.queue_rows_bound = (uint32_t)std::min<uint64_t>((uint64_t)c->tiles_local * 64, 0x7fffffffull);
     }
     HIP_TRY(c, hipEventRecord(c->ev0, st));     // ev0..ev1 bracket the render kernel alone (roofline.achieved)
     HIP_TRY(c, launch_render(p, (uint32_t)c->n_cu, c->count_traversal ? 1 : 0, st));

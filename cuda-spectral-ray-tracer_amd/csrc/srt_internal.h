@@ -43,7 +43,8 @@ struct RenderParams {
     uint32_t fringe_threshold;            // lanes at fringe records wait until this many of them can share a triangle step
     const uint32_t *tile_order;           // optional: queue slot -> local tile (cost-descending order); null = identity
     uint32_t *tile_cost;                  // probe mode: per local tile, node records visited by its pixels
-    const uint32_t *sched;                // optional: queue positions below sched[0] / [1] / [2] are cost class 3 / 2 / 1
+    const uint32_t *queue_rows;           // optional: [0] = number of queue rows (device-written by order_tiles_kernel)
+    uint32_t queue_rows_bound;            // host-side upper bound of the row count (= tiles_local without splitting)
     uint32_t waves_per_cu_override;       // 0 = occupancy API
     uint32_t debug_lane_limit;            // experiments only (env SRT_DEBUG_LANE_LIMIT): lanes >= limit of every tile stay idle
     // state / outputs
@@ -63,7 +64,8 @@ struct ScatterParams {
 
 hipError_t launch_init_rng(uint32_t *rng, uint32_t n_lanes, uint64_t seed, hipStream_t st);
 hipError_t launch_render(const RenderParams &p, uint32_t n_cu, int mode, hipStream_t st);   // mode 0 render, 1 instrumented, 2 cost probe
-hipError_t launch_order_tiles(const uint32_t *cost, uint32_t *order, uint32_t n, uint32_t *sched, hipStream_t st);
+hipError_t launch_order_tiles(const uint32_t *cost, uint32_t *sorted, uint32_t *rows, uint32_t n, uint32_t n_waves,
+                              uint32_t split_load_pct, uint32_t *queue_info, hipStream_t st);
 hipError_t launch_scatter(const ScatterParams &p, hipStream_t st);
 hipError_t launch_unswizzle(const float *const src[3], float *const dst[3], uint32_t tx, uint32_t ty, uint32_t bx, uint32_t by,
                             uint32_t n_cols, uint32_t n_rows, uint32_t offx, uint32_t offy, uint32_t image_width,

@@ -30,7 +30,7 @@ constexpr int kLdsTablesF4 = kLdsUniF4 + kLdsCmfF4 + kLdsBgF2 / 2;
 struct LdsUniforms {
     float du[3], dv[3], p00[3], center[3], disk_u[3], disk_v[3], defocus_angle;
     uint32_t width, height, offx, offy, tx, ty, bx, by, tiles_x, n_tiles, rank, world, spp, n_lanes;
-    uint32_t sched[3];
+    uint32_t n_rows;          // queue length in rows of 64 pixel slots (= tiles_local unless expensive tiles were split)
     uint32_t lane_limit;
     uint32_t rng[2], tile_out[2], tile_order[2], tile_cost[2], pixel_counter[2];
 };
@@ -126,9 +126,9 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
         for (int a = 0; a < 3; a++) {
             U->du[a] = P.du[a]; U->dv[a] = P.dv[a]; U->p00[a] = P.p00[a]; U->center[a] = P.center[a];
             U->disk_u[a] = P.disk_u[a]; U->disk_v[a] = P.disk_v[a];
-            U->sched[a] = P.sched ? P.sched[a] : 0u;
         }
         U->defocus_angle = P.defocus_angle;
+        U->n_rows = P.queue_rows ? P.queue_rows[0] : P.tiles_local;   // written by order_tiles_kernel earlier on this stream
         U->lane_limit = P.debug_lane_limit ? P.debug_lane_limit : 64u;
         U->width = P.width; U->height = P.height; U->offx = P.offx; U->offy = P.offy;
         U->tx = P.tx; U->ty = P.ty; U->bx = P.bx; U->by = P.by;
@@ -154,7 +154,6 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
     ns.lds_q0 = (lds_cf4 *)s_q0; ns.lds_q1 = (lds_cf4 *)s_q1; ns.lds_q2 = (lds_cf4 *)s_q2;
     ns.lds_r0 = (lds_cu32 *)s_r0; ns.lds_r1 = (lds_cu32 *)s_r1;
     ns.n_cached = P.n_cached;
-    const uint32_t n_local_pixels = P.tiles_local * 64u;
     const uint32_t spp = P.spp;
     StackRef my_stack;
     {
@@ -167,7 +166,7 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
     bool dead = false, have_path = false, result_ready = false, have_pixel = false;
     uint32_t idx = 0;                       // block-linear index of the current pixel (RNG / framebuffer slot)
     uint32_t out_slot = 0;                  // tile_local * 576 + lane_in_tile
-    V3 pixel_center = mk(0.f, 0.f, 0.f);
+    uint32_t pixel_ij = 0;                  // chunk-relative column | row << 16 (both are 16-bit quantities, Q17)
     Rng rs; rs.d = rs.v0 = rs.v1 = rs.v2 = rs.v3 = rs.v4 = 0u;
     V3 acc = mk(0.f, 0.f, 0.f);             // pixel_color (rendering.cu:212)
     uint32_t sample = 0, bounce = 0, valid = 0;
@@ -179,19 +178,22 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
     Trav tv; tv.node = -1; tv.sp = 0; tv.top = -1; tv.c = kFltMax; tv.hit = -1; tv.nf[0] = tv.nf[1] = tv.nf[2] = 0u;
     uint32_t n_rays = 0;
     TravStats ts;
-    // latency mode (see the traversal phase): cost class of this lane's pixel, from the probe
-    uint32_t lane_class = 0;
-    uint32_t wave_class = ~0u;
+    // Rows of an expensive tile that was split over several waves (see order_tiles_kernel) are exclusive: the lanes whose
+    // slot is not part of the row's share, and the lanes that finish early, stay PARKED until every pixel of the wave is
+    // done -- a wave that refilled itself with other pixels would slow the expensive chains down again.
+    bool parked = false, exclusive = false;
     unsigned long long t_shade = 0, t_inner = 0, t_fringe = 0, t_mark = 0;   // instrumented build: wave cycles per phase
     if (COUNT) t_mark = __builtin_amdgcn_s_memtime();
     uint32_t cur_tile_local = 0, pixel_iters0 = 0;   // probe / instrumented builds
     uint32_t pixel_rays0 = 0, max_pix_iters = 0, max_pix_rays = 0;
 
     for (;;) {
+        // parked lanes wake up when no lane of the wave holds a pixel any more
+        if (__ballot(have_pixel) == 0ull) parked = false;
         // =========================== shading phase ===========================================================
-        // every lane that is neither traversing nor dead goes through: shade -> path end -> pixel switch ->
+        // every lane that is neither traversing nor dead nor parked goes through: shade -> path end -> pixel switch ->
         // camera ray -> start traversal.  The loop repeats only in corner cases (bounce_limit 0, leaf-root BVH).
-        while (__ballot(!dead && tv.node < 0) != 0ull) {
+        while (__ballot(!dead && !parked && tv.node < 0) != 0ull) {
             bool end_path = false, begin_trav = false;
 
             // ---- S1: shade a finished closest-hit query: one iteration of ray_bounce's loop (rendering.cu:22-36)
@@ -305,7 +307,7 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
             }
 
             // ---- S3: pixel switch: all samples of the current pixel done (or no pixel yet) ------------------------
-            if (!dead && tv.node < 0 && !have_path && !begin_trav && (!have_pixel || sample == spp)) {
+            if (!dead && !parked && tv.node < 0 && !have_path && !begin_trav && (!have_pixel || sample == spp)) {
                 if (have_pixel && PROBE) {
                     // cost of this pixel = node records it visited (+1 so that empty pixels still sort after real ones)
                     atomicAdd(join_ptr<uint32_t>(U->tile_cost[0], U->tile_cost[1]) + cur_tile_local, ts.n_iters - pixel_iters0 + 1u);
@@ -337,6 +339,7 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
                 }
                 // fetch the next pixel of this rank's queue (wave-aggregated atomic); skip slots outside the chunk
                 bool searching = true;
+                if (exclusive) { parked = true; exclusive = false; searching = false; }   // wait for the rest of the split row
                 while (searching) {
                     const unsigned long long m = __ballot(1);
                     const int leader = __ffsll((long long)m) - 1;
@@ -344,13 +347,24 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
                     if ((int)lane == leader) base = atomicAdd(join_ptr<uint32_t>(U->pixel_counter[0], U->pixel_counter[1]), (uint32_t)__popcll(m));
                     base = (uint32_t)__shfl((int)base, leader, 64);
                     const uint32_t pix = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                    if (pix >= n_local_pixels) { dead = true; searching = false; }
+                    if (pix >= U->n_rows * 64u) { dead = true; searching = false; }
                     else {
-                        const uint32_t qp = pix;
+                        // queue row = tile | part << 22 | s << 28: the row covers lanes [part * (64 >> s), (part + 1) * (64 >> s))
+                        // of the tile (s = 0: the whole tile).  Cost-descending order, see order_tiles_kernel.
                         const uint32_t *tile_order = join_ptr<const uint32_t>(U->tile_order[0], U->tile_order[1]);
-                        const uint32_t tile_local = tile_order ? tile_order[qp >> 6] : (qp >> 6);   // cost-ordered queue
-                        lane_class = (qp >> 6) < U->sched[0] ? 3u : ((qp >> 6) < U->sched[1] ? 2u : ((qp >> 6) < U->sched[2] ? 1u : 0u));
-                        const uint32_t lt = qp & 63u;
+                        const uint32_t row = tile_order ? tile_order[pix >> 6] : (pix >> 6);
+                        const uint32_t tile_local = row & 0x3fffffu, row_part = (row >> 22) & 63u, row_s = (row >> 28) & 7u;
+                        const uint32_t lt = pix & 63u;
+                        // A split row is meant for a wave that takes it whole (all 64 lanes fetch together: first fill, or
+                        // after an exclusive row).  Then the lanes outside the row's share park.  A lane that refills on its own
+                        // and lands in a split row just skips a slot that is not the row's share, and renders one that is like
+                        // any other pixel.
+                        const bool whole_wave = m == ~0ull;
+                        if ((lt >> (6u - row_s)) != row_part) {
+                            if (whole_wave) { parked = true; searching = false; }
+                            continue;
+                        }
+                        exclusive = whole_wave && row_s != 0u;
                         const uint32_t tile = U->rank + U->world * tile_local;
                         const uint32_t tiles_x = U->tiles_x;
                         const uint32_t tile_x = tile % tiles_x, tile_y = tile / tiles_x;
@@ -361,9 +375,7 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
                         if ((tile < U->n_tiles) && (lt < U->lane_limit) && (i < U->width) && (j < U->height) && (i / gtx < gbx) && (j / gty < U->by)) {
                             idx = block_linear_idx(i, j, gtx, gty, gbx);
                             out_slot = tile_local * (uint32_t)(kTilePlanes * kTileLanes) + lt;
-                            // pixel_center = p00 + (float)i*du + (float)j*dv, i/j incl. the chunk offset (rendering.cu:76,221)
-                            const V3 du = mk(U->du[0], U->du[1], U->du[2]), dv = mk(U->dv[0], U->dv[1], U->dv[2]);
-                            pixel_center = (mk(U->p00[0], U->p00[1], U->p00[2]) + (float)(U->offx + i) * du) + (float)(U->offy + j) * dv;
+                            pixel_ij = i | (j << 16);
                             {
                                 const uint32_t *rng = join_ptr<const uint32_t>(U->rng[0], U->rng[1]);      // rendering.cu:209
                                 const size_t nl = U->n_lanes;
@@ -387,6 +399,9 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
                 float py = -0.5f + rng_uniform(rs);
                 const V3 du = mk(U->du[0], U->du[1], U->du[2]), dv = mk(U->dv[0], U->dv[1], U->dv[2]);
                 const V3 cam_center = mk(U->center[0], U->center[1], U->center[2]);
+                // pixel_center = p00 + (float)i*du + (float)j*dv, i/j incl. the chunk offset (rendering.cu:76,221); recomputed per
+                // camera ray from the packed pixel coordinates instead of living in three registers
+                const V3 pixel_center = (mk(U->p00[0], U->p00[1], U->p00[2]) + (float)(U->offx + (pixel_ij & 0xffffu)) * du) + (float)(U->offy + (pixel_ij >> 16)) * dv;
                 V3 pixel_sample = pixel_center + (px * du + py * dv);
                 V3 origin = cam_center;
                 if (!(U->defocus_angle <= 0.0f)) {                          // defocus_disk_sample, :42-47
@@ -427,31 +442,14 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
         // Two kinds of steps: INNER (record with two internal children: box tests only) and FRINGE (a leaf child:
         // box + triangle tests, several times the cost).  Lanes that reach a fringe record wait until
         // P.fringe_threshold of them can share one fringe step, or until no lane has inner work left.
-        const unsigned long long alive_mask = __ballot(!dead);
-        if (alive_mask == 0ull) break;
-        // Latency mode.  A pixel is one sequential chain (its RNG stream), so the launch cannot end before its most expensive
-        // pixel does -- at cfg 3 one pixel needs 678 k node visits, 11x the mean.  Waves that hold expensive pixels (cost class
-        // from the probe) therefore trade throughput for latency: they raise their issue priority over the other waves of
-        // the SIMD and stop batching (the shade / fringe thresholds shrink to 1 for the top class).
-        {
-            const uint32_t wc = __ballot(!dead && lane_class == 3u) ? 3u : (__ballot(!dead && lane_class >= 2u) ? 2u : (__ballot(!dead && lane_class >= 1u) ? 1u : 0u));
-            if (wc != wave_class) {
-                wave_class = wc;
-                if (wc == 3u) __builtin_amdgcn_s_setprio(3);
-                else if (wc == 2u) __builtin_amdgcn_s_setprio(2);
-                else if (wc == 1u) __builtin_amdgcn_s_setprio(1);
-                else __builtin_amdgcn_s_setprio(0);
-            }
-        }
-        int shade_thr = wave_class == 3u ? 1 : (wave_class == 2u ? max(1, (int)P.shade_threshold / 8) : (wave_class == 1u ? max(1, (int)P.shade_threshold / 2) : (int)P.shade_threshold));
-        int fringe_thr = wave_class == 3u ? 1 : (wave_class == 2u ? max(1, (int)P.fringe_threshold / 8) : (wave_class == 1u ? max(1, (int)P.fringe_threshold / 2) : (int)P.fringe_threshold));
-        {
-            // the batching thresholds are fractions of the lanes that still have work: a wave in the tail of the launch
-            // (queue empty, most lanes retired) must not wait for 32 idle lanes that will never come
-            const int n_alive = __popcll(alive_mask);
-            shade_thr = max(1, (shade_thr * n_alive) >> 6);
-            fringe_thr = max(1, (fringe_thr * n_alive) >> 6);
-        }
+        if (__ballot(!dead) == 0ull) break;
+        const unsigned long long alive_mask = __ballot(!dead && !parked);
+        if (alive_mask == 0ull) continue;     // only parked lanes left: wake them up
+        // the batching thresholds are fractions of the lanes that currently own work: a wave in the tail of the launch
+        // (queue empty, most lanes retired) or one that hosts a split row must not wait for idle lanes that never come
+        const int n_alive = __popcll(alive_mask);
+        const int shade_thr = max(1, ((int)P.shade_threshold * n_alive) >> 6);
+        const int fringe_thr = max(1, ((int)P.fringe_threshold * n_alive) >> 6);
         for (;;) {
             const unsigned long long trav_mask = __ballot(tv.node >= 0);
             if (trav_mask == 0ull) break;
@@ -513,18 +511,29 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
     }
 }
 
-// Cost-descending order of the local tiles for the pixel queue (longest-processing-time-first), on the device so that
-// srt_render_chunk never has to synchronise with the host: one workgroup, 4096-bin counting sort on the probe's per-tile
-// cost.  The order inside a bin is arbitrary -- it only affects scheduling, never results.
-__global__ __launch_bounds__(1024) void order_tiles_kernel(const uint32_t *__restrict__ cost, uint32_t *__restrict__ order, uint32_t n,
-                                                          uint32_t *__restrict__ sched) {
+// Pixel queue of one launch, built on the device so that srt_render_chunk never has to synchronise with the host.
+//
+// 1. Cost-descending order of the local tiles (longest-processing-time-first): 4096-bin counting sort on the probe's
+//    per-tile cost.  The order inside a bin is arbitrary -- it only affects scheduling, never results.
+// 2. Splitting.  A pixel is one sequential chain (all its samples draw from one RNG stream), so the launch cannot end
+//    before its most expensive pixel does, and 64 such pixels in one wave slow each other down further (a step serves one
+//    kind of work): measured on cfg 3, the most expensive tile alone takes 242 ms with 64 pixels per wave, 209 / 192 / 186 /
+//    166 / 107 ms with 16 / 8 / 4 / 2 / 1.  When the launch is chain-bound -- few tiles per wave: a small chunk, or one
+//    rank's share of a multi-GPU frame -- the tiles whose estimated latency exceeds the launch's estimated makespan are
+//    split into 2^s rows of 64 >> s pixels, each row taken by a different wave.  With many tiles per wave (one GPU, full
+//    frame) the makespan estimate is far above any tile and nothing is split.
+//    queue row = tile | part << 22 | s << 28;  queue_info[0] = number of rows.
+__global__ __launch_bounds__(1024) void order_tiles_kernel(const uint32_t *__restrict__ cost, uint32_t *__restrict__ sorted,
+                                                          uint32_t *__restrict__ rows, uint32_t n, uint32_t n_waves,
+                                                          uint32_t split_load_pct, uint32_t *__restrict__ queue_info) {
     constexpr uint32_t kBinsN = 4096;
     __shared__ uint32_t s_bin[kBinsN];
     __shared__ uint32_t s_max;
     __shared__ unsigned long long s_sum;
-    __shared__ uint32_t s_cls[3];
+    __shared__ uint32_t s_scan[1024];
+    __shared__ float s_load;
     const uint32_t t = threadIdx.x;
-    if (t == 0) { s_max = 1u; s_sum = 0ull; s_cls[0] = s_cls[1] = s_cls[2] = 0u; }
+    if (t == 0) { s_max = 1u; s_sum = 0ull; }
     for (uint32_t b = t; b < kBinsN; b += 1024) s_bin[b] = 0u;
     __syncthreads();
     uint32_t m = 0;
@@ -533,23 +542,68 @@ __global__ __launch_bounds__(1024) void order_tiles_kernel(const uint32_t *__res
     atomicMax(&s_max, m);
     atomicAdd(&s_sum, sum);
     __syncthreads();
-    // cost classes for the latency mode of the render kernel: tiles costing >= 8x / 4x / 2x the mean tile
-    const unsigned long long mean = s_sum / (n ? n : 1u) + 1ull;
-    uint32_t c3 = 0, c2 = 0, c1 = 0;
-    for (uint32_t k = t; k < n; k += 1024) { const unsigned long long c = cost[k]; c3 += c >= 8 * mean; c2 += c >= 4 * mean; c1 += c >= 2 * mean; }
-    atomicAdd(&s_cls[0], c3); atomicAdd(&s_cls[1], c2); atomicAdd(&s_cls[2], c1);
     const float scale = (float)(kBinsN - 1) / (float)s_max;
     auto bin_of = [&](uint32_t c) { uint32_t b = (uint32_t)((float)c * scale); b = b > kBinsN - 1 ? kBinsN - 1 : b; return (kBinsN - 1) - b; };   // bin 0 = most expensive
     for (uint32_t k = t; k < n; k += 1024) atomicAdd(&s_bin[bin_of(cost[k])], 1u);
     __syncthreads();
-    if (t == 0) {       // exclusive scan of 4096 counters: trivial next to a multi-second render
+    if (t == 0) {       // exclusive scan of 4096 counters: trivial next to the render
         uint32_t acc = 0;
         for (uint32_t b = 0; b < kBinsN; b++) { const uint32_t c = s_bin[b]; s_bin[b] = acc; acc += c; }
     }
     __syncthreads();
-    for (uint32_t k = t; k < n; k += 1024) order[atomicAdd(&s_bin[bin_of(cost[k])], 1u)] = k;
-    // queue positions below sched[i] belong to class 3 - i (the queue is cost-descending up to the bin width)
-    if (t == 0) { sched[0] = s_cls[0]; sched[1] = s_cls[1]; sched[2] = s_cls[2]; }
+    for (uint32_t k = t; k < n; k += 1024) sorted[atomicAdd(&s_bin[bin_of(cost[k])], 1u)] = k;
+    __syncthreads();
+
+    // latency of a tile relative to the same tile at 64 pixels per wave, by split level (pixels per wave 64 .. 1)
+    const float g[7] = {1.0f, 0.957f, 0.863f, 0.794f, 0.767f, 0.687f, 0.442f};
+    auto level_for = [&](uint32_t c, float target) {
+        uint32_t s = 0;
+        while (s < 6u && (float)c * g[s] > target) s++;
+        return s;
+    };
+    // Makespan target T (cost units): the smallest T such that (a) every row's latency c * g[s] fits into T with the
+    // smallest possible split level s(c, T), and (b) the rows fit the machine: sum over rows of their latency -- a row
+    // holds a wave slot for that long however few lanes it uses -- times a load factor <= n_waves * T.  Splitting buys
+    // latency with wave-slot time (a tile cut into 64 single-pixel rows costs 28x its unsplit slot time), so (b) is what
+    // keeps a throughput-bound launch from splitting anything.  Bisection; every step is one parallel reduction.
+    const bool may_split = split_load_pct != 0u && n <= 0x3fffffu;
+    float target = 3.0e38f;
+    if (may_split) {
+        const float load_factor = (float)split_load_pct * 0.01f;
+        float lo_t = (float)s_max * g[6], hi_t = fmaxf((float)s_max, load_factor * (float)s_sum / (float)(n_waves ? n_waves : 1u));
+        for (int it = 0; it < 14; it++) {
+            const float mid = 0.5f * (lo_t + hi_t);
+            float load = 0.f;
+            for (uint32_t k = t; k < n; k += 1024) { const uint32_t c = cost[k]; const uint32_t s = level_for(c, mid); load += (float)(1u << s) * (float)c * g[s]; }
+            if (t == 0) s_load = 0.f;
+            __syncthreads();
+            atomicAdd(&s_load, load);
+            __syncthreads();
+            const bool feasible = load_factor * s_load <= (float)n_waves * mid;
+            __syncthreads();
+            if (feasible) hi_t = mid; else lo_t = mid;
+        }
+        target = hi_t;
+    }
+    auto level_of = [&](uint32_t c) { return may_split ? level_for(c, target) : 0u; };
+    // rows per thread over a contiguous piece of the sorted order, then a scan
+    const uint32_t per = (n + 1023u) / 1024u;
+    const uint32_t lo = min(n, t * per), hi = min(n, lo + per);
+    uint32_t mine = 0;
+    for (uint32_t k = lo; k < hi; k++) mine += 1u << level_of(cost[sorted[k]]);
+    s_scan[t] = mine;
+    __syncthreads();
+    if (t == 0) {
+        uint32_t acc = 0;
+        for (uint32_t b = 0; b < 1024u; b++) { const uint32_t c = s_scan[b]; s_scan[b] = acc; acc += c; }
+        queue_info[0] = acc;
+    }
+    __syncthreads();
+    uint32_t at = s_scan[t];
+    for (uint32_t k = lo; k < hi; k++) {
+        const uint32_t tile = sorted[k], s = level_of(cost[tile]);
+        for (uint32_t part = 0; part < (1u << s); part++) rows[at++] = tile | (part << 22) | (s << 28);
+    }
 }
 
 // Gathered compact tiles -> block-linear planar framebuffer (rendering.cu:146-148 layout).
@@ -683,7 +737,7 @@ static hipError_t launch_render_mode(const RenderParams &p_in, uint32_t n_cu, hi
     // persistent waves: fill every CU (16 waves per CU at this kernel's register budget), never more waves than tiles
     uint32_t waves_per_cu = p.waves_per_cu_override > 0 ? p.waves_per_cu_override : 16u;
     uint32_t n_waves = n_cu * waves_per_cu;
-    if (n_waves > p.tiles_local) n_waves = p.tiles_local;
+    if (n_waves > p.queue_rows_bound) n_waves = p.queue_rows_bound;     // never more waves than queue rows (upper bound known to the host)
     const uint32_t n_blocks = (n_waves + (uint32_t)wpb - 1) / (uint32_t)wpb;
     hipLaunchKernelGGL((render_kernel<MODE, NARROW>), dim3(n_blocks), dim3(64 * wpb), lds, st, p);
     return hipGetLastError();
@@ -697,9 +751,10 @@ hipError_t launch_render(const RenderParams &p, uint32_t n_cu, int mode, hipStre
     return narrow ? launch_render_mode<0, true>(p, n_cu, st) : launch_render_mode<0, false>(p, n_cu, st);
 }
 
-hipError_t launch_order_tiles(const uint32_t *cost, uint32_t *order, uint32_t n, uint32_t *sched, hipStream_t st) {
+hipError_t launch_order_tiles(const uint32_t *cost, uint32_t *sorted, uint32_t *rows, uint32_t n, uint32_t n_waves,
+                              uint32_t split_load_pct, uint32_t *queue_info, hipStream_t st) {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(order_tiles_kernel, dim3(1), dim3(1024), 0, st, cost, order, n, sched);
+    hipLaunchKernelGGL(order_tiles_kernel, dim3(1), dim3(1024), 0, st, cost, sorted, rows, n, n_waves, split_load_pct, queue_info);
     return hipGetLastError();
 }
 

@@ -165,6 +165,30 @@ def test_partition_invariance_and_chunks(srt, gpu, orc):
     gpu.set_partition(0, 1)
 
 
+def test_queue_scheduling_does_not_change_results(srt, gpu, orc, monkeypatch):
+    """The pixel queue (cost order, expensive tiles split over several waves with parked lanes) is pure scheduling: the
+    framebuffer is bit-identical with splitting off, with the default policy and with the most aggressive policy, and for
+    different batching thresholds."""
+    scene = srt.Scene.builtin(srt.SCENE_RANDOM_SPHERES).build_bvh(srt.BVH_SAH, 1984)
+    W, H, spp, depth = 120, 72, 12, 16          # spp > 8: the cost probe and the ordered queue are active
+    cam = scene.default_camera(W, H)
+    ref = None
+    for env in ({"SRT_SPLIT_LOAD": "0"}, {}, {"SRT_SPLIT_LOAD": "1"}, {"SRT_SPLIT_LOAD": "1", "SRT_SHADE_THRESHOLD": "3", "SRT_FRINGE_THRESHOLD": "60"},
+                {"SRT_PROBE_SPP": "0"}):
+        for k in ("SRT_SPLIT_LOAD", "SRT_SHADE_THRESHOLD", "SRT_FRINGE_THRESHOLD", "SRT_PROBE_SPP"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        r = srt.Renderer(0)                       # the knobs are read when the context is created
+        img = srt.render_image(scene, cam, W, H, spp, depth, renderer=r)
+        if ref is None:
+            ref = img
+        else:
+            assert_planes_equal(img["fb"], ref["fb"], "env %r" % (env,))
+            assert_planes_equal(img["xyz"], ref["xyz"], "env %r xyz" % (env,))
+        del r
+
+
 def test_second_render_continues_rng_streams(srt, gpu, orc):
     """RNG states persist between launches (rendering.cu:209,232; Q13): two renders of spp each differ from each other and
     the second equals the oracle continued from the first one's states."""
