@@ -274,11 +274,36 @@ int build_bvh_sah(srt_scene &s) {
                                  [&](int32_t a, int32_t b) { return cx[a] < cx[b]; });
             }
         }
+        // Child order.  The traversal is the reference's: always left first (bvh.cu:154-160), so the order is a property of
+        // the tree.  Put the half that is nearer to the scene's camera on the left: camera rays then meet their closest hit
+        // early and closest_so_far prunes the far half -- the effect of a front-to-back traversal for 40 % of the rays,
+        // without touching the traversal order.
+        bool second_first = false;
+        {
+            Box a, b; a.reset(); b.reset();
+            for (size_t k = cur.start; k < mid; k++) a.grow(s.rec[order[k]].box);
+            for (size_t k = mid; k < cur.end; k++) b.grow(s.rec[order[k]].box);
+            auto dist2 = [&](const Box &bx) {
+                double d2 = 0;
+                for (int ax = 0; ax < 3; ax++) {
+                    const double p = s.cam.lookfrom[ax];
+                    const double d = p < bx.lo[ax] ? bx.lo[ax] - p : (p > bx.hi[ax] ? p - bx.hi[ax] : 0.0);
+                    d2 += d * d;
+                }
+                return d2;
+            };
+            second_first = dist2(b) < dist2(a);
+        }
         const int32_t l = (int32_t)s.nodes.size();
         s.nodes.emplace_back(); s.nodes.emplace_back();
         s.nodes[cur.node].left = l; s.nodes[cur.node].right = l + 1;
-        stack.push_back({mid, cur.end, l + 1});
-        stack.push_back({cur.start, mid, l});
+        if (second_first) {
+            stack.push_back({cur.start, mid, l + 1});
+            stack.push_back({mid, cur.end, l});
+        } else {
+            stack.push_back({mid, cur.end, l + 1});
+            stack.push_back({cur.start, mid, l});
+        }
     }
     finish_boxes_and_depth(s);
     s.bvh_valid = true;
