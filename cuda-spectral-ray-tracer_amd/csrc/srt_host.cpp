@@ -222,7 +222,9 @@ int build_bvh_sah(srt_scene &s) {
     s.nodes.emplace_back();
     s.root = 0;
     stack.push_back({0, n, 0});
-    constexpr int kBins = 32;
+    constexpr int kMaxBins = 256;
+    // 128 bins: V (node records per ray, cfg 3) 17.6 with 32 bins, 17.0 with 128, 16.4 with 256; build time is linear in it
+    const int kBins = getenv("SRT_SAH_BINS") ? std::min(kMaxBins, std::max(2, atoi(getenv("SRT_SAH_BINS")))) : 128;
     while (!stack.empty()) {
         const Span cur = stack.back();
         stack.pop_back();
@@ -238,7 +240,7 @@ int build_bvh_sah(srt_scene &s) {
             for (int a = 0; a < 3; a++) {
                 const float ext = chi[a] - clo[a];
                 if (!(ext > 0)) continue;
-                Box bb[kBins]; size_t cnt[kBins];
+                Box bb[kMaxBins]; size_t cnt[kMaxBins];
                 for (int b = 0; b < kBins; b++) { bb[b].reset(); cnt[b] = 0; }
                 const float scale = (float)kBins / ext;
                 for (size_t k = cur.start; k < cur.end; k++) {
@@ -246,7 +248,7 @@ int build_bvh_sah(srt_scene &s) {
                     b = std::min(std::max(b, 0), kBins - 1);
                     bb[b].grow(s.rec[order[k]].box); cnt[b]++;
                 }
-                double right_area[kBins]; size_t right_cnt[kBins];
+                double right_area[kMaxBins]; size_t right_cnt[kMaxBins];
                 Box acc; acc.reset(); size_t c = 0;
                 for (int b = kBins - 1; b > 0; b--) { acc.grow(bb[b]); c += cnt[b]; right_area[b] = acc.area(); right_cnt[b] = c; }
                 acc.reset(); c = 0;
