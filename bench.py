@@ -207,8 +207,9 @@ def main():
             "metric": "Mray/s", "value": mray, "unit": "Mray/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "random-spheres tri scene (%d tris, %d BVH nodes, %s tree), %dx%d, %d spp, depth %d" %
-                                   (scene.n_tris, scene.n_nodes, "SAH" if args.bvh == 1 else "reference", W, H, args.spp, args.depth),
+            "config": {"workload": "%s (%d tris, %d BVH nodes, %s tree), %dx%d, %d spp, depth %d" %
+                                   ({0: "reference CORNELL scene", 1: "reference PRISM scene", 2: "reference TRIS scene", 100: "random-spheres tri scene",
+                                     101: "100k-triangle mesh in the Cornell shell"}.get(args.scene, "scene %d" % args.scene), scene.n_tris, scene.n_nodes, "SAH" if args.bvh == 1 else "reference", W, H, args.spp, args.depth),
                        "scene_id": args.scene, "tiles": "8x8 px per wave, rank = tile % n_gpus", "gather": "1 RCCL gather of compact tiles"},
             "mpath_per_s": (W * H * args.spp * steps) / elapsed / 1e6,
             "rays_per_path": rays_per_path, "node_records_per_ray_V": V, "tri_tests_per_ray_T": T, "algorithmic_bytes_per_ray": b_ray,

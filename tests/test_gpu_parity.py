@@ -245,3 +245,45 @@ def test_full_size_blocks_bit_exact(srt, gpu, orc):
     # lanes the oracle did not render stay zero there; the GPU image is complete: no pixel of the image is left unwritten
     rm = gpu.read_fb_rowmajor(W, H)
     assert min(float(p.max()) for p in rm) > 0 and all(np.isfinite(p).all() for p in rm)
+
+
+def _blocks_bit_exact(srt, gpu, orc, sid, mode, W, H, spp, depth, block_lo, stride, max_blocks):
+    import os
+    scene = srt.Scene.builtin(sid, 0).build_bvh(mode, 1984)
+    cam = scene.default_camera(W, H)
+    gpu.upload_scene(scene); gpu.set_camera(cam); gpu.set_partition(0, 1)
+    gpu.init_device_params(W, H, spp, depth, 1984)
+    gpu.set_count_traversal(False)
+    gpu.render_chunk(W, H)
+    gpu.scatter_tiles()
+    fb, xyz = gpu.read_fb(), gpu.read_fb_aux(2)
+    g = gpu.geom
+    n_blocks = g["bx"] * g["by"]
+    osc = oracle_scene_for(orc, scene, mode)
+    threads = min(os.cpu_count() or 1, 16)
+    ref = osc.render(cam, W, H, spp, depth, block_lo=block_lo, block_stride=stride, threads=threads)
+    checked = 0
+    for b in range(block_lo, n_blocks, stride):
+        sl = slice(b * 448, (b + 1) * 448)
+        for c in range(3):
+            assert np.array_equal(bits(xyz[c][sl]), bits(ref["xyz"][c][sl])), ("block", b, "plane", c)
+            assert np.array_equal(fb[c][sl], ref["fb"][c][sl]), ("block", b, "plane", c)
+        checked += 1
+    assert 1 <= checked <= max_blocks
+    rm = gpu.read_fb_rowmajor(W, H)
+    assert all(np.isfinite(p).all() for p in rm)
+    return checked
+
+
+def test_full_size_prism_blocks_bit_exact(srt, gpu, orc):
+    """BASELINE cfg 4 at FULL size: the reference's PRISM scene (Sellmeier flint with quirk Q1, hero wavelengths, reference
+    BVH builder), 1920x1080, 2048 spp, depth 16; four of the 28x16 blocks through the middle of the image against the
+    oracle at full spp, bit for bit."""
+    assert _blocks_bit_exact(srt, gpu, orc, srt.SCENE_PRISM, srt.BVH_REFERENCE, 1920, 1080, 2048, 16, 1200, 700, 6) >= 4
+
+
+def test_full_resolution_mesh100k_blocks_bit_exact(srt, gpu, orc):
+    """BASELINE cfg 5's scene and resolution (100k-triangle mesh in the Cornell shell, 3840x2160, depth 16; inner tree larger
+    than LDS, 32-bit record references) at 64 spp instead of 4096 -- the full sample count is tens of GPU-seconds and minutes of
+    oracle time per block; the code path does not depend on spp beyond the loop count (cfg 3's test runs 1024)."""
+    assert _blocks_bit_exact(srt, gpu, orc, srt.SCENE_MESH100K, srt.BVH_SAH, 3840, 2160, 64, 16, 2000, 4100, 6) >= 4
