@@ -1,0 +1,9 @@
+#!/bin/bash
+# numbers behind DESIGN.md section 6 (run through gpurun): per-GPU time of rank 0's share, lone tile / pixel latencies
+for W in 1 2 3 4 8; do
+  for S in 0 220; do
+    echo -n "world $W split_load $S: "; SRT_SPLIT_LOAD=$S timeout -k 10 120 python tools/diag.py --spp 1024 --world $W --rank 0 2>/dev/null | grep '"ms"'
+  done
+done
+python tools/chain.py 2>/dev/null | grep "most expensive"
+for p in 64 32 16 8 4 2 1; do SRT_DEBUG_LANE_LIMIT=$p timeout -k 10 100 python tools/lone_tile.py ${TILE_ARGS:-} 2>&1 | grep lane_limit; done
