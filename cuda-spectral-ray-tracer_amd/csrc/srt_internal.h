@@ -46,6 +46,7 @@ struct RenderParams {
     const uint32_t *queue_rows;           // optional: [0] = number of queue rows (device-written by order_tiles_kernel)
     uint32_t queue_rows_bound;            // host-side upper bound of the row count (= tiles_local without splitting)
     uint32_t waves_per_cu_override;       // 0 = occupancy API
+    uint32_t score_shade, score_fringe;   // step-choice weights, 256 / relative step cost (score_shade 0 = threshold rule)
     uint32_t debug_lane_limit;            // experiments only (env SRT_DEBUG_LANE_LIMIT): lanes >= limit of every tile stay idle
     // state / outputs
     uint32_t *rng;                        // SoA: 6 planes of n_lanes words, indexed by the block-linear idx

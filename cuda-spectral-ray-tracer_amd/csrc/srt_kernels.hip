@@ -453,9 +453,19 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
         for (;;) {
             const unsigned long long trav_mask = __ballot(tv.node >= 0);
             if (trav_mask == 0ull) break;
-            if (__popcll(alive_mask & ~trav_mask) >= shade_thr) break;
             const unsigned long long fringe_mask = __ballot(tv.node >= P.n_inner);
-            const bool do_fringe = (__popcll(fringe_mask) >= fringe_thr) || (fringe_mask == trav_mask);
+            bool do_fringe;
+            if (P.score_shade != 0u) {
+                // serve the kind of work with the most waiting lanes per unit of step cost (weights: srt_capi.cpp)
+                const uint32_t s_sh = (uint32_t)__popcll(alive_mask & ~trav_mask) * P.score_shade;
+                const uint32_t s_fr = (uint32_t)__popcll(fringe_mask) * P.score_fringe;
+                const uint32_t s_in = (uint32_t)__popcll(trav_mask & ~fringe_mask) << 8;
+                if (s_sh > s_fr && s_sh > s_in) break;
+                do_fringe = s_fr > s_in;
+            } else {
+                if (__popcll(alive_mask & ~trav_mask) >= shade_thr) break;
+                do_fringe = (__popcll(fringe_mask) >= fringe_thr) || (fringe_mask == trav_mask);
+            }
             if (COUNT) { ts.w_iters++; ts.w_alive += (uint32_t)__popcll(alive_mask); if (do_fringe) { ts.w_fringe++; ts.l_fringe += (uint32_t)__popcll(fringe_mask); } else ts.l_inner += (uint32_t)__popcll(trav_mask & ~fringe_mask); }
             if (do_fringe) {
                 if (tv.node >= P.n_inner) {
