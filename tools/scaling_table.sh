@@ -1,8 +1,8 @@
 #!/bin/bash
 # numbers behind DESIGN.md section 6 (run through gpurun): per-GPU time of rank 0's share, lone tile / pixel latencies
 for W in 1 2 3 4 8; do
-  for S in 0 220; do
-    echo -n "world $W split_load $S: "; SRT_SPLIT_LOAD=$S timeout -k 10 120 python tools/diag.py --spp 1024 --world $W --rank 0 2>/dev/null | grep '"ms"'
+  for S in 0 default; do
+    echo -n "world $W split_load $S: "; if [ $S = default ]; then unset SRT_SPLIT_LOAD; else export SRT_SPLIT_LOAD=$S; fi; timeout -k 10 120 python tools/diag.py --spp 1024 --world $W --rank 0 2>/dev/null | grep '"ms"'
   done
 done
 python tools/chain.py 2>/dev/null | grep "most expensive"
