@@ -19,6 +19,7 @@
 #include <semaphore>
 #include <string>
 #include <thread>
+#include <vector>
 
 #include "../../include/srt_c_api.h"
 
@@ -182,17 +183,19 @@ private:
     bool device_inited = false;
 };
 
-// rendering/render_manager.cuh:9-35
+// rendering/render_manager.cuh:9-35: one of the two hand-off slots between the render thread and the caller
 struct render_step_data {
     render_step_data() : empty(1), full(0) {}
+    void alloc_buffer(size_t buffer_size) { fb_r.assign(buffer_size, 0.f); fb_g.assign(buffer_size, 0.f); fb_b.assign(buffer_size, 0.f); }
+    std::vector<float> fb_r, fb_g, fb_b;      // block-linear, grid sized (what the three D2H copies of step() deliver)
     uint starting_offset_x = 0, starting_offset_y = 0, chunk_width = 0, chunk_height = 0;
     std::counting_semaphore<1> empty, full;   // utils/multithread.cuh:3
     bool is_last = false;
 };
 
-// rendering/render_manager.cuh:37-224 + render_manager.cu.  The staging copy + CPU un-swizzle of the reference
-// (three grid-sized D2H copies, then a 2M-iteration div/mod loop) is replaced by one device un-swizzle kernel
-// writing straight into the row-major frame_buffer planes (srt_read_fb_rowmajor).
+// rendering/render_manager.cuh:37-224 + render_manager.cu.  Same structure as the reference: render_cycle() starts a
+// render thread that produces chunks into two slots (step), the caller consumes them with update_fb(), which un-swizzles
+// the block-linear planes into the row-major frame_buffer; `empty` / `full` semaphores order the two sides.
 class render_manager {
 public:
     render_manager(const srt_scene *_scene, camera *_cam, frame_buffer *_fb) {
@@ -215,6 +218,7 @@ public:
         uint y_chunks = (uint)std::ceil(float(image_height) / float(chunk_height));
         n_iterations = x_chunks * y_chunks;
         r.init_device_params(threads, blocks, chunk_width, chunk_height);
+        for (auto &rd : render_data_container) rd.alloc_buffer((size_t)threads.x * blocks.x * threads.y * blocks.y);   // render_manager.cu:82-83
         device_inited = r.isDeviceInited();   // reference sets true unconditionally; here a missing GPU must not look ready
     }
     void init_device_params(uint _chunk_width, uint _chunk_height) {   // render_manager.cu:91-102
@@ -234,8 +238,7 @@ public:
         rd->chunk_width = last_chunk_width; rd->chunk_height = last_chunk_height;
         rd->starting_offset_x = offset_x; rd->starting_offset_y = offset_y;
         r.render(last_chunk_width, last_chunk_height, offset_x, offset_y);
-        // the device framebuffer holds this chunk until the next render(): un-swizzle it into fb now
-        srt_read_fb_rowmajor(r.getContext(), fb->r, fb->g, fb->b, image_width, image_height);
+        srt_read_fb(r.getContext(), rd->fb_r.data(), rd->fb_g.data(), rd->fb_b.data());   // the three D2H copies, render_manager.cu:41-45
         srt_stats st;
         if (srt_get_stats(r.getContext(), &st) == SRT_OK) total_rays += st.rays;
         bool last_step = false;
@@ -246,10 +249,24 @@ public:
         offset_y = (i / x_chunks) * chunk_height;
         return !last_step;
     }
-    bool update_fb() {   // render_manager.cuh:68-142: hand-off only, pixels are already in fb
+    bool update_fb() {   // render_manager.cuh:68-142
         render_step_data *rd = &render_data_container[next_read_render_data_index];
         next_read_render_data_index = (next_read_render_data_index + 1) % 2;
         rd->full.acquire();
+        // un-swizzle: lane idx = thread_y * threads.x + thread_x + block_size * (block_y * blocks.x + block_x) holds chunk pixel
+        // (threads.x * block_x + thread_x, threads.y * block_y + thread_y); pixels outside the chunk were never written
+        const uint block_size = threads.x * threads.y;
+        for (uint y = 0; y < rd->chunk_height && y < threads.y * blocks.y; y++) {
+            const uint block_y = y / threads.y, thread_y = y % threads.y;
+            float *dr = fb->r + (size_t)(y + rd->starting_offset_y) * image_width + rd->starting_offset_x;
+            float *dg = fb->g + (size_t)(y + rd->starting_offset_y) * image_width + rd->starting_offset_x;
+            float *db = fb->b + (size_t)(y + rd->starting_offset_y) * image_width + rd->starting_offset_x;
+            for (uint x = 0; x < rd->chunk_width && x < threads.x * blocks.x; x++) {
+                const uint block_x = x / threads.x, thread_x = x % threads.x;
+                const size_t idx = (size_t)thread_y * threads.x + thread_x + (size_t)block_size * ((size_t)block_y * blocks.x + block_x);
+                dr[x] = rd->fb_r[idx]; dg[x] = rd->fb_g[idx]; db[x] = rd->fb_b[idx];
+            }
+        }
         const bool last_read = rd->is_last;
         rd->empty.release();
         return !last_read;
