@@ -220,7 +220,7 @@ def main():
                                  "LDS/L2-resident, so these bytes never reach HBM (traffic = measured HBM bytes per launch, "
                                  "profiles/r01/hbm_traffic.json): the kernel is VALU / L1-gather bound, a frac above 1 is possible"},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:     # the CPU baseline is reported at N=1 only
             try:
                 out["cpu_baseline"] = cpu_baseline(srt, scene, cam, W, H, args.depth, args.bvh)
             except Exception as e:   # the checker is optional for the measurement itself
