@@ -16,13 +16,12 @@
 
 namespace srt {
 
-// LDS map of one workgroup (W waves): [0, 1536) colour matching rows (96 float4) | [1536, 2304) background pairs
-// (96 float2) | inner-record cache: three float4 planes + one (16-bit refs) or two u32 planes of n_cached entries |
-// W traversal stacks, each stack_depth * 64 lanes * (2 or 4) B, lane-interleaved.
+// LDS map of one workgroup (W waves): 256 B launch uniforms | colour matching rows (96 float4) | inner-record cache: three
+// float4 planes + one (16-bit refs) or two u32 planes of n_cached entries | W traversal stacks, each
+// stack_depth * 64 lanes * (2 or 4) B, lane-interleaved.
 constexpr int kLdsUniF4 = 16;          // 256 B block of launch-uniform values that only the cold paths read (see LdsUniforms)
 constexpr int kLdsCmfF4 = 96;
-constexpr int kLdsBgF2 = 96;
-constexpr int kLdsTablesF4 = kLdsUniF4 + kLdsCmfF4 + kLdsBgF2 / 2;
+constexpr int kLdsTablesF4 = kLdsUniF4 + kLdsCmfF4;
 
 // Launch-uniform values used only by the pixel-switch / camera-ray blocks.  Kept in LDS instead of SGPRs: the persistent
 // loop has ~190 live scalars otherwise, and the allocator spilled 80 of them into VGPR lanes, putting dozens of
@@ -112,7 +111,6 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
     extern __shared__ float4 lds4[];
     lds_uniforms *U = (lds_uniforms *)lds4;
     float4 *s_cmf = lds4 + kLdsUniF4;
-    float2 *s_bg = reinterpret_cast<float2 *>(lds4 + kLdsUniF4 + kLdsCmfF4);
     constexpr bool narrow = NARROW;           // P.n_records <= 65535 (launcher): 16-bit child references and stack entries
     const uint32_t nc = (uint32_t)P.n_cached;
     float4 *s_q0 = lds4 + kLdsTablesF4, *s_q1 = s_q0 + nc, *s_q2 = s_q1 + nc;
@@ -137,7 +135,6 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
         split_ptr(P.tile_cost, U->tile_cost); split_ptr(P.pixel_counter, U->pixel_counter);
     }
     for (uint32_t k = threadIdx.x; k < kLdsCmfF4; k += blockDim.x) s_cmf[k] = P.cmf[k];
-    for (uint32_t k = threadIdx.x; k < kLdsBgF2; k += blockDim.x) s_bg[k] = P.bg_sd[k];
     for (uint32_t k = threadIdx.x; k < nc; k += blockDim.x) {
         s_q0[k] = P.nodes[4 * k + 0]; s_q1[k] = P.nodes[4 * k + 1]; s_q2[k] = P.nodes[4 * k + 2];
         const float4 q3 = P.nodes[4 * k + 3];
@@ -201,17 +198,12 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
                 result_ready = false;
                 float wl[kWavelengths];
                 hero_expand(hero, wl);
+                // the spectrum this segment multiplies into the path: the background on a miss (rendering.cu:24-27), the hit
+                // material's reflectance otherwise (material.cu:95) -- one look-up site for both
+                const float2 *sd = P.bg_sd;
+                bool was_hit = false, hit_scattered = false;
                 if (tv.hit < 0) {
-                    // miss: r.mul_spectrum(background) and stop (rendering.cu:24-27)
-#pragma unroll
-                    for (int k = 0; k < kWavelengths; k++) {
-                        if ((uint32_t)k < valid) {
-                            int off; float w;
-                            interp_coords(wl[k], off, w);
-                            pw[k] *= interp_pair(s_bg[off], w);
-                        }
-                    }
-                    end_path = true;
+                    end_path = true;        // miss: r.mul_spectrum(background) and stop
                 } else {
                     // rebuild the hit record from (t, triangle): tri::hit tail (tri.cu:36-39) + set_face_normal
                     const int tri = tv.hit;
@@ -262,19 +254,23 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
                             if (near_zero(scatter_direction)) scatter_direction = n;
                         }
                     }
-                    // r_in.mul_spectrum(spectral_distribution) (:95), after valid_wavelengths was updated (Q8)
-                    const float2 *sd = P.mat_sd + (size_t)mat * 96u;
-#pragma unroll
-                    for (int k = 0; k < kWavelengths; k++) {
-                        if ((uint32_t)k < valid) {
-                            int off; float w;
-                            interp_coords(wl[k], off, w);
-                            pw[k] *= interp_pair(sd[off], w);
-                        }
-                    }
+                    sd = P.mat_sd + (size_t)mat * 96u;
                     ro = hp + (eps_sign * kEpsilon) * n;                                    // :96 (Q9)
                     rd = scatter_direction;                                                 // :97
-                    if (!did_scatter) {
+                    hit_scattered = did_scatter;
+                    was_hit = true;
+                }
+                // r_in.mul_spectrum(spectral_distribution) (:95), after valid_wavelengths was updated (Q8)
+#pragma unroll
+                for (int k = 0; k < kWavelengths; k++) {
+                    if ((uint32_t)k < valid) {
+                        int off; float w;
+                        interp_coords(wl[k], off, w);
+                        pw[k] *= interp_pair(sd[off], w);
+                    }
+                }
+                if (was_hit) {
+                    if (!hit_scattered) {
                         end_path = true;
                     } else {
                         bounce++;
