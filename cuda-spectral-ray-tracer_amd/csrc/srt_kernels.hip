@@ -730,8 +730,9 @@ static hipError_t launch_render_mode(const RenderParams &p_in, uint32_t n_cu, hi
     RenderParams p = p_in;
     int wpb = 1, n_cached = 0;
     render_launch_shape(p.stack_depth, p.n_records, p.n_inner, wpb, n_cached);
-    if (p.waves_per_cu_override > 0 && p.waves_per_cu_override < 16) {   // experiment knob: smaller groups, no cache sharing
-        wpb = 1; n_cached = 0;
+    if (p.waves_per_cu_override > 0 && p.waves_per_cu_override < 16 && wpb == 16) {
+        // experiment knob: fewer waves per CU (one smaller workgroup per CU, same LDS cache), e.g. 8 = two waves per SIMD
+        wpb = (int)p.waves_per_cu_override;
     }
     p.n_cached = n_cached;
     const size_t lds = render_lds_bytes(p.stack_depth, wpb, n_cached, p.n_records);
