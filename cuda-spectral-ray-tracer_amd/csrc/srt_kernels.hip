@@ -97,10 +97,12 @@ __global__ void init_rng_kernel(uint32_t *rng, uint32_t n_lanes, uint64_t seed) 
 //   RESULT (result_ready)                 traversal finished, hit record waits to be shaded
 //   IDLE   (!have_path)                   needs a new camera ray, or a new pixel when its samples are used up
 //   DEAD                                  pixel queue drained
-// The wave alternates between a traversal phase (all TRAV lanes step together; it ends when P.shade_threshold lanes
-// are waiting, so slow rays do not hold the other lanes hostage) and a shading phase (RESULT / IDLE lanes are
-// shaded, regenerated and re-armed).  Pixels are handed out by one wave-aggregated atomic per refill; which lane
-// renders a pixel has no influence on the result (the RNG stream belongs to the pixel).
+//   PARKED                                split queue rows only: waits until the wave's expensive pixels are done
+// The wave alternates between traversal steps (INNER or FRINGE: a step serves the lanes that sit at that kind of record)
+// and shading passes (RESULT / IDLE lanes are shaded, regenerated and re-armed); what it does next is the kind of work
+// with the most waiting lanes per unit of cost, so slow rays do not hold the other lanes hostage.  Pixels are handed
+// out by one wave-aggregated atomic per refill; which lane renders a pixel has no influence on the result (the RNG
+// stream belongs to the pixel).
 // MODE 0: production; MODE 1: instrumented (counts V / T / utilisation); MODE 2: cost probe -- renders P.spp samples per
 // pixel from a COPY of the RNG state, writes nothing but the per-tile traversal cost used to order the pixel queue.
 template <int MODE, bool NARROW>
