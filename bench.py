@@ -35,7 +35,7 @@ def log(msg):
     print("[bench] " + msg, file=sys.stderr, flush=True)
 
 
-def cpu_baseline(srt, scene, cam, width, height, depth, mode, budget_s=20.0):
+def cpu_baseline(srt, scene, cam, width, height, depth, mode, budget_s=20.0, gpu_renderer=None):
     """The oracle (kind "port") on all host cores, same scene/camera/size, reduced spp (rate is spp independent)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_binding as O
@@ -54,8 +54,17 @@ def cpu_baseline(srt, scene, cam, width, height, depth, mode, budget_s=20.0):
     r = osc.render(cam, width, height, spp, depth, threads=cores)
     dt = time.time() - t0
     st = r["stats"]
-    return {"value": st["rays"] / dt / 1e6, "unit": "Mray/s", "cores": cores, "kind": "port",
-            "sample": "%dx%d, %d spp, depth %d, same scene/camera/BVH, %d threads, %.1f s" % (width, height, spp, depth, cores, dt)}
+    out = {"value": st["rays"] / dt / 1e6, "unit": "Mray/s", "cores": cores, "kind": "port",
+           "sample": "%dx%d, %d spp, depth %d, same scene/camera/BVH, %d threads, %.1f s" % (width, height, spp, depth, cores, dt)}
+    if gpu_renderer is not None:
+        # the same frame at the same spp on the GPU: per-channel L-inf of the unquantised sRGB planes (BASELINE's parity
+        # metric, target <= 1e-3) and the number of lanes whose bits differ -- the checker at work, outside the timed region
+        import numpy as np
+        g = srt.render_image(scene, cam, width, height, spp, depth, renderer=gpu_renderer)
+        linf = [float(np.max(np.abs(a - b))) for a, b in zip(g["lin"], r["lin"])]
+        nbits = int(sum(int(np.count_nonzero(a.view(np.uint32) != b.view(np.uint32))) for a, b in zip(g["xyz"], r["xyz"])))
+        out["parity"] = {"linf_rgb": linf, "lanes_with_different_bits": nbits, "spp": spp, "rays_equal": bool(g["stats"]["rays"] == st["rays"])}
+    return out
 
 
 def main():
@@ -222,7 +231,7 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:     # the CPU baseline is reported at N=1 only
             try:
-                out["cpu_baseline"] = cpu_baseline(srt, scene, cam, W, H, args.depth, args.bvh)
+                out["cpu_baseline"] = cpu_baseline(srt, scene, cam, W, H, args.depth, args.bvh, gpu_renderer=r)
             except Exception as e:   # the checker is optional for the measurement itself
                 out["cpu_baseline"] = {"value": None, "unit": "Mray/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %r" % (e,)}
         print(json.dumps(out), flush=True)
