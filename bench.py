@@ -227,7 +227,8 @@ def main():
                          "traffic": traffic,
                          "note": "achieved = algorithmic bytes (V*64 + T*48 + 56 per ray) / render-kernel time. The scene is "
                                  "LDS/L2-resident, so these bytes never reach HBM (traffic = measured HBM bytes per launch, "
-                                 "profiles/r01/hbm_traffic.json): the kernel is VALU / L1-gather bound, a frac above 1 is possible"},
+                                 "profiles/r01/hbm_traffic.json): the kernel is bound by VALU issue (96 % busy at 26 of 64 lanes per instruction, "
+                                 "profiles/r01/v8_pmc_summary_64spp.txt), a frac above 1 is possible"},
         }
         if not args.no_cpu_baseline and world == 1:     # the CPU baseline is reported at N=1 only
             try:
