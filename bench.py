@@ -99,6 +99,8 @@ def main():
         raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
     if args.rehearse_gloo:
         local_rank = 0
+    if local_rank >= torch.cuda.device_count():      # launcher restricted each rank's visible devices to its own GPU
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
