@@ -448,6 +448,19 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
         const int n_alive = __popcll(alive_mask);
         const int shade_thr = max(1, ((int)P.shade_threshold * n_alive) >> 6);
         const int fringe_thr = max(1, ((int)P.fringe_threshold * n_alive) >> 6);
+        if (!COUNT && n_alive == 1) {
+            // A wave with ONE working lane (a single-pixel row of a split tile, or the tail of the launch) has nothing to
+            // schedule: walk the ray to the end in a tight loop.  Such waves are latency chains -- every instruction of the
+            // step-choice logic is on the critical path of the pixel that bounds a chain-bound launch.
+            while (__ballot(tv.node >= 0) != 0ull) {
+                if (tv.node >= 0) {
+                    if (tv.node < P.n_inner) trav_step_inner<ITERS, NARROW>(tv, ns, ro, inv, my_stack, ts);
+                    else trav_step_fringe<ITERS, NARROW>(tv, ns, ro, rd, inv, my_stack, ts);
+                    if (tv.node < 0) result_ready = true;
+                }
+            }
+            continue;
+        }
         for (;;) {
             const unsigned long long trav_mask = __ballot(tv.node >= 0);
             if (trav_mask == 0ull) break;
