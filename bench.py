@@ -60,7 +60,8 @@ def cpu_baseline(srt, scene, cam, width, height, depth, mode, budget_s=20.0, gpu
         # the same frame at the same spp on the GPU: per-channel L-inf of the unquantised sRGB planes (BASELINE's parity
         # metric, target <= 1e-3) and the number of lanes whose bits differ -- the checker at work, outside the timed region
         import numpy as np
-        g = srt.render_image(scene, cam, width, height, spp, depth, renderer=gpu_renderer)
+        # (instrumented kernel variant: keeps the production kernel's rocprof average to the timed launches)
+        g = srt.render_image(scene, cam, width, height, spp, depth, renderer=gpu_renderer, count_traversal=True)
         linf = [float(np.max(np.abs(a - b))) for a, b in zip(g["lin"], r["lin"])]
         nbits = int(sum(int(np.count_nonzero(a.view(np.uint32) != b.view(np.uint32))) for a, b in zip(g["xyz"], r["xyz"])))
         out["parity"] = {"linf_rgb": linf, "lanes_with_different_bits": nbits, "spp": spp, "rays_equal": bool(g["stats"]["rays"] == st["rays"])}
