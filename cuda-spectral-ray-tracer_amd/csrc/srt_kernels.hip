@@ -194,6 +194,7 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
         // camera ray -> start traversal.  The loop repeats only in corner cases (bounce_limit 0, leaf-root BVH).
         while (__ballot(!dead && !parked && tv.node < 0) != 0ull) {
             bool end_path = false, begin_trav = false;
+            float xyz_x = 0.0f, xyz_y = 0.0f, xyz_z = 0.0f;      // XYZ of a path that ends in this pass
 
             // ---- S1: shade a finished closest-hit query: one iteration of ray_bounce's loop (rendering.cu:22-36)
             if (!dead && tv.node < 0 && result_ready) {
@@ -262,13 +263,25 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
                     hit_scattered = did_scatter;
                     was_hit = true;
                 }
-                // r_in.mul_spectrum(spectral_distribution) (:95), after valid_wavelengths was updated (Q8)
+                // r_in.mul_spectrum(spectral_distribution) (:95), after valid_wavelengths was updated (Q8).  A path that ends
+                // here (miss, or no scattered ray) is converted in the same loop: dev_spectrum_to_XYZ (color.cu:88-104) needs
+                // the same interpolation coordinates.  (A path that ends because the bounce limit is reached contributes
+                // nothing: valid_wavelengths = 0, rendering.cu:38.)
+                const bool ends_here = !was_hit || !hit_scattered;
+                const float delta_lambda = (kLambdaMax - kLambdaMin) / (float)kWavelengths;
 #pragma unroll
                 for (int k = 0; k < kWavelengths; k++) {
                     if ((uint32_t)k < valid) {
                         int off; float w;
                         interp_coords(wl[k], off, w);
                         pw[k] *= interp_pair(sd[off], w);
+                        if (ends_here) {
+                            const float4 r0 = s_cmf[off], r1 = s_cmf[off + 1];
+                            const float power = pw[k];
+                            xyz_x += ((1.0f - w) * r0.x + w * r1.x) * power * delta_lambda;
+                            xyz_y += ((1.0f - w) * r0.y + w * r1.y) * power * delta_lambda;
+                            xyz_z += ((1.0f - w) * r0.z + w * r1.z) * power * delta_lambda;
+                        }
                     }
                 }
                 if (was_hit) {
@@ -284,23 +297,7 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
 
             // ---- S2: path end: pixel_color += dev_spectrum_to_XYZ(...) (rendering.cu:227, color.cu:88-104) --------
             if (end_path) {
-                float wl[kWavelengths];
-                hero_expand(hero, wl);
-                const float delta_lambda = (kLambdaMax - kLambdaMin) / (float)kWavelengths;
-                float x = 0.0f, y = 0.0f, z = 0.0f;
-#pragma unroll
-                for (int k = 0; k < kWavelengths; k++) {
-                    if ((uint32_t)k < valid) {
-                        int off; float w;
-                        interp_coords(wl[k], off, w);
-                        const float4 r0 = s_cmf[off], r1 = s_cmf[off + 1];
-                        const float power = pw[k];
-                        x += ((1.0f - w) * r0.x + w * r1.x) * power * delta_lambda;
-                        y += ((1.0f - w) * r0.y + w * r1.y) * power * delta_lambda;
-                        z += ((1.0f - w) * r0.z + w * r1.z) * power * delta_lambda;
-                    }
-                }
-                acc = acc + mk(x, y, z);
+                acc = acc + mk(xyz_x, xyz_y, xyz_z);
                 have_path = false;
             }
 
