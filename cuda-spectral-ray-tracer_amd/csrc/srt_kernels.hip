@@ -584,7 +584,8 @@ __global__ __launch_bounds__(1024) void order_tiles_kernel(const uint32_t *__res
     // holds a wave slot for that long however few lanes it uses -- times a load factor <= n_waves * T.  Splitting buys
     // latency with wave-slot time (a tile cut into 64 single-pixel rows costs 28x its unsplit slot time), so (b) is what
     // keeps a throughput-bound launch from splitting anything.  Bisection; every step is one parallel reduction.
-    const bool may_split = split_load_pct != 0u && n <= 0x3fffffu;
+    // (also keeps 64 * rows far below 2^32: the queue head is a 32-bit pixel-slot counter)
+    const bool may_split = split_load_pct != 0u && n <= (1u << 20);
     float target = 3.0e38f;
     if (may_split) {
         const float load_factor = (float)split_load_pct * 0.01f;
