@@ -255,7 +255,7 @@ int srt_render_chunk(srt_ctx *c, uint32_t width, uint32_t height, uint32_t offx,
     // (longest-processing-time-first), the most expensive ones split over several waves when the launch is chain-bound.
     p.tile_order = nullptr; p.tile_cost = nullptr; p.queue_rows = nullptr; p.queue_rows_bound = c->tiles_local;
     p.debug_lane_limit = c->debug_lane_limit;
-    const bool ordered = c->probe_spp > 0 && c->spp > 4 * c->probe_spp && c->tiles_local > 1;
+    const bool ordered = c->probe_spp > 0 && c->spp > 4 * c->probe_spp && c->tiles_local > 1 && c->tiles_local <= 0x3fffffu;   // 22-bit tile field of a queue row
     if (ordered) {
         if (c->tiles_local > c->tile_sched_capacity) {
             if (c->d_tile_cost) { (void)hipFree(c->d_tile_cost); c->d_tile_cost = nullptr; }
