@@ -41,6 +41,12 @@ class Stats(C.Structure):
                 ("box_tests", C.c_uint64), ("util", C.c_uint64 * 9), ("reserved", C.c_uint64 * 2)]
 
 
+class Calibration(C.Structure):
+    _fields_ = [("wave_cycles_mean", C.c_double), ("wave_cycles_max", C.c_double), ("wall_ms", C.c_double),
+                ("instr_per_wave", C.c_uint64), ("n_waves", C.c_uint32), ("n_cu", C.c_uint32), ("waves_per_simd", C.c_uint32),
+                ("reserved", C.c_uint32)]
+
+
 assert C.sizeof(Material) == 428 and C.sizeof(CameraData) == 84 and C.sizeof(TriIn) == 44
 
 # every symbol include/srt_c_api.h declares: name -> (restype, argtypes)
@@ -92,6 +98,7 @@ PROTOTYPES = {
     "srt_last_kernel_ms": (_i, [_vp, C.POINTER(_f)]),
     "srt_trace_rays": (_i, [_vp, _fp, _sz, _fp]),
     "srt_device_op_sweep": (_i, [_vp, _i, _fp, _fp, _sz, _fp]),
+    "srt_calibrate": (_i, [_vp, _i, _u32, _u32, C.POINTER(Calibration)]),
 }
 
 

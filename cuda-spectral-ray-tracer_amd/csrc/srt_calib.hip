@@ -1,0 +1,132 @@
+// srt_calib.hip -- issue-rate calibration microkernels for gfx950 (the denominator of bench.py's roofline).
+//
+// The render kernel is a divergent VALU/LDS program, not a memory stream: what bounds it is how many wave64 vector
+// instructions a SIMD can issue per cycle with the four resident waves this kernel runs (127 VGPRs -> 4 waves / SIMD).
+// That rate is measured here instead of assumed: each kernel runs one long loop of independent (or deliberately
+// dependent) instructions written in inline asm, every wave stamps s_memtime around its loop, and the host adds a
+// HIP-event wall time so that cycles turn into seconds at the clock the chip really holds under that load.
+//
+// kinds (8 instructions per asm block, 4 blocks per loop trip):
+//   0 v_add_f32, 8 independent accumulators          1 v_pk_mul_f32, 8 independent accumulator pairs
+//   2 v_fma_f32, 8 independent accumulators          3 v_add_f32, ONE dependent chain
+//   4 s_add_u32, 8 independent scalars               5 4 x (v_add_f32 + s_add_u32) interleaved (co-issue)
+//   6 v_cmp_lt_f32 + v_cndmask_b32 pairs (VCC)       7 ds_read_b64, lane-linear addresses (conflict free)
+//   8 ds_read_b64, per-lane random 16-byte records   9 v_max3_f32, 8 independent accumulators
+//  10 v_add_f32 with only 26 of 64 lanes enabled (EXEC-masked: does a partially filled instruction cost less?)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "srt_internal.h"
+
+namespace srt {
+
+constexpr int kCalibKinds = 11;
+
+#define REP4(x) x x x x
+
+template <int KIND>
+__global__ __launch_bounds__(1024) void calib_kernel(uint32_t iters, float *sink, unsigned long long *cycles) {
+    extern __shared__ float4 lds4[];
+    const uint32_t tid = threadIdx.x;
+    float a0 = (float)tid, a1 = a0 + 1.f, a2 = a0 + 2.f, a3 = a0 + 3.f, a4 = a0 + 4.f, a5 = a0 + 5.f, a6 = a0 + 6.f, a7 = a0 + 7.f;
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 p0 = {a0, a1}, p1 = {a1, a2}, p2 = {a2, a3}, p3 = {a3, a4}, p4 = {a4, a5}, p5 = {a5, a6}, p6 = {a6, a7}, p7 = {a7, a0};
+    const float k = 1.0000001f;
+    const f2 k2 = {k, k};
+    uint32_t s0 = iters, s1 = 1, s2 = 2, s3 = 3, s4 = 4, s5 = 5, s6 = 6, s7 = 7;
+    // LDS image for kinds 7 / 8: 64 KB of floats
+    if (KIND == 7 || KIND == 8) {
+        float *l = reinterpret_cast<float *>(lds4);
+        for (uint32_t i = tid; i < 16384u; i += blockDim.x) l[i] = (float)i;
+        __syncthreads();
+    }
+    uint32_t lin_addr = (tid & 63u) * 8u;                               // conflict-free ds_read_b64
+    uint32_t rnd_addr = ((tid * 2654435761u) >> 20) * 16u;              // 4096 records of 16 B, hashed per lane
+    unsigned long long saved_exec = 0;
+    if (KIND == 10) asm volatile("s_mov_b64 %0, exec\n s_mov_b64 exec, 0x3ffffff" : "=s"(saved_exec));
+    __builtin_amdgcn_sched_barrier(0);
+    unsigned long long t0;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1
+    for (uint32_t i = 0; i < iters; i++) {
+        if (KIND == 0 || KIND == 10) {
+            REP4(asm volatile("v_add_f32 %0, %0, %8\n v_add_f32 %1, %1, %8\n v_add_f32 %2, %2, %8\n v_add_f32 %3, %3, %8\n"
+                              "v_add_f32 %4, %4, %8\n v_add_f32 %5, %5, %8\n v_add_f32 %6, %6, %8\n v_add_f32 %7, %7, %8\n"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(k));)
+        } else if (KIND == 1) {
+            REP4(asm volatile("v_pk_mul_f32 %0, %0, %8\n v_pk_mul_f32 %1, %1, %8\n v_pk_mul_f32 %2, %2, %8\n v_pk_mul_f32 %3, %3, %8\n"
+                              "v_pk_mul_f32 %4, %4, %8\n v_pk_mul_f32 %5, %5, %8\n v_pk_mul_f32 %6, %6, %8\n v_pk_mul_f32 %7, %7, %8\n"
+                              : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7) : "v"(k2));)
+        } else if (KIND == 2) {
+            REP4(asm volatile("v_fma_f32 %0, %0, %8, %8\n v_fma_f32 %1, %1, %8, %8\n v_fma_f32 %2, %2, %8, %8\n v_fma_f32 %3, %3, %8, %8\n"
+                              "v_fma_f32 %4, %4, %8, %8\n v_fma_f32 %5, %5, %8, %8\n v_fma_f32 %6, %6, %8, %8\n v_fma_f32 %7, %7, %8, %8\n"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(k));)
+        } else if (KIND == 3) {
+            REP4(asm volatile("v_add_f32 %0, %0, %1\n v_add_f32 %0, %0, %1\n v_add_f32 %0, %0, %1\n v_add_f32 %0, %0, %1\n"
+                              "v_add_f32 %0, %0, %1\n v_add_f32 %0, %0, %1\n v_add_f32 %0, %0, %1\n v_add_f32 %0, %0, %1\n"
+                              : "+v"(a0) : "v"(k));)
+        } else if (KIND == 4) {
+            REP4(asm volatile("s_add_u32 %0, %0, 1\n s_add_u32 %1, %1, 1\n s_add_u32 %2, %2, 1\n s_add_u32 %3, %3, 1\n"
+                              "s_add_u32 %4, %4, 1\n s_add_u32 %5, %5, 1\n s_add_u32 %6, %6, 1\n s_add_u32 %7, %7, 1\n"
+                              : "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3), "+s"(s4), "+s"(s5), "+s"(s6), "+s"(s7)::"scc");)
+        } else if (KIND == 5) {
+            REP4(asm volatile("v_add_f32 %0, %0, %8\n s_add_u32 %4, %4, 1\n v_add_f32 %1, %1, %8\n s_add_u32 %5, %5, 1\n"
+                              "v_add_f32 %2, %2, %8\n s_add_u32 %6, %6, 1\n v_add_f32 %3, %3, %8\n s_add_u32 %7, %7, 1\n"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+s"(s4), "+s"(s5), "+s"(s6), "+s"(s7) : "v"(k) : "scc");)
+        } else if (KIND == 6) {
+            REP4(asm volatile("v_cmp_lt_f32 vcc, %0, %4\n v_cndmask_b32 %0, %0, %4, vcc\n v_cmp_lt_f32 vcc, %1, %4\n v_cndmask_b32 %1, %1, %4, vcc\n"
+                              "v_cmp_lt_f32 vcc, %2, %4\n v_cndmask_b32 %2, %2, %4, vcc\n v_cmp_lt_f32 vcc, %3, %4\n v_cndmask_b32 %3, %3, %4, vcc\n"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(k) : "vcc");)
+        } else if (KIND == 7 || KIND == 8) {
+            const uint32_t addr = KIND == 7 ? lin_addr : rnd_addr;
+            REP4(asm volatile("ds_read_b64 %0, %8\n ds_read_b64 %1, %8 offset:512\n ds_read_b64 %2, %8 offset:1024\n ds_read_b64 %3, %8 offset:1536\n"
+                              "ds_read_b64 %4, %8 offset:2048\n ds_read_b64 %5, %8 offset:2560\n ds_read_b64 %6, %8 offset:3072\n ds_read_b64 %7, %8 offset:3584\n"
+                              "s_waitcnt lgkmcnt(0)\n"
+                              : "=&v"(p0), "=&v"(p1), "=&v"(p2), "=&v"(p3), "=&v"(p4), "=&v"(p5), "=&v"(p6), "=&v"(p7) : "v"(addr) : "memory");)
+        } else if (KIND == 9) {
+            REP4(asm volatile("v_max3_f32 %0, %0, %8, %1\n v_max3_f32 %1, %1, %8, %2\n v_max3_f32 %2, %2, %8, %3\n v_max3_f32 %3, %3, %8, %4\n"
+                              "v_max3_f32 %4, %4, %8, %5\n v_max3_f32 %5, %5, %8, %6\n v_max3_f32 %6, %6, %8, %7\n v_max3_f32 %7, %7, %8, %0\n"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(k));)
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    unsigned long long t1;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (KIND == 10) asm volatile("s_mov_b64 exec, %0" ::"s"(saved_exec));
+    const uint32_t gwave = (blockIdx.x * blockDim.x + tid) >> 6;
+    if ((tid & 63u) == 0u) cycles[gwave] = t1 - t0;
+    // keep every accumulator alive
+    float acc = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + p0.x + p1.y + p2.x + p3.y + p4.x + p5.y + p6.x + p7.y +
+                (float)(s0 + s1 + s2 + s3 + s4 + s5 + s6 + s7);
+    if (acc == 12345.678f) sink[tid] = acc;
+}
+
+template <int KIND>
+static hipError_t run_kind(uint32_t n_blocks, uint32_t threads, uint32_t iters, float *sink, unsigned long long *cycles, hipStream_t st) {
+    const size_t lds = 96 * 1024;      // more than half a CU's LDS: exactly one workgroup per CU, so waves / SIMD = threads / 256
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&calib_kernel<KIND>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((calib_kernel<KIND>), dim3(n_blocks), dim3(threads), lds, st, iters, sink, cycles);
+    return hipGetLastError();
+}
+
+hipError_t launch_calib(int kind, uint32_t n_blocks, uint32_t threads, uint32_t iters, float *sink, unsigned long long *cycles, hipStream_t st) {
+    switch (kind) {
+    case 0: return run_kind<0>(n_blocks, threads, iters, sink, cycles, st);
+    case 1: return run_kind<1>(n_blocks, threads, iters, sink, cycles, st);
+    case 2: return run_kind<2>(n_blocks, threads, iters, sink, cycles, st);
+    case 3: return run_kind<3>(n_blocks, threads, iters, sink, cycles, st);
+    case 4: return run_kind<4>(n_blocks, threads, iters, sink, cycles, st);
+    case 5: return run_kind<5>(n_blocks, threads, iters, sink, cycles, st);
+    case 6: return run_kind<6>(n_blocks, threads, iters, sink, cycles, st);
+    case 7: return run_kind<7>(n_blocks, threads, iters, sink, cycles, st);
+    case 8: return run_kind<8>(n_blocks, threads, iters, sink, cycles, st);
+    case 9: return run_kind<9>(n_blocks, threads, iters, sink, cycles, st);
+    case 10: return run_kind<10>(n_blocks, threads, iters, sink, cycles, st);
+    default: return hipErrorInvalidValue;
+    }
+}
+int calib_kinds() { return kCalibKinds; }
+
+}  // namespace srt

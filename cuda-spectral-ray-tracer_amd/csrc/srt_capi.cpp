@@ -54,6 +54,8 @@ struct srt_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
     uint64_t last_paths = 0;
+    float *d_rowmajor = nullptr;                        // row-major staging image of srt_read_fb_rowmajor (3 planes)
+    uint32_t rowmajor_w = 0, rowmajor_h = 0;
 };
 
 namespace {
@@ -121,7 +123,7 @@ int srt_create(int device, srt_ctx **out) {
     if (const char *ev = getenv("SRT_WAVES_PER_CU")) c->waves_per_cu = (uint32_t)std::max(0, atoi(ev));
     if (const char *ev = getenv("SRT_PROBE_SPP")) c->probe_spp = (uint32_t)std::max(0, atoi(ev));
     if (const char *ev = getenv("SRT_SCORE_SHADE")) c->score_shade = (uint32_t)std::max(0, atoi(ev));
-    if (const char *ev = getenv("SRT_SCORE_FRINGE")) c->score_fringe = (uint32_t)std::max(0, atoi(ev));
+    if (const char *ev = getenv("SRT_SCORE_FRINGE")) c->score_fringe = (uint32_t)std::max(1, atoi(ev));   // 0 would starve fringe lanes
     if (const char *ev = getenv("SRT_DEBUG_LANE_LIMIT")) c->debug_lane_limit = (uint32_t)std::max(0, atoi(ev));
     if (const char *ev = getenv("SRT_SPLIT_LOAD")) c->split_load_pct = (uint32_t)std::max(0, atoi(ev));
     if (const char *ev = getenv("SRT_FRINGE_THRESHOLD")) c->fringe_threshold = (uint32_t)std::max(1, atoi(ev));
@@ -148,7 +150,7 @@ void srt_destroy(srt_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    void *bufs[] = {c->d_nodes, c->d_fringe, c->d_tris, c->d_mat_sd, c->d_mat_par, c->d_bg, c->d_cmf, c->d_rng, c->d_fb, c->d_tiles, c->d_counters, c->d_tile_cost, c->d_tile_order};
+    void *bufs[] = {c->d_nodes, c->d_fringe, c->d_tris, c->d_mat_sd, c->d_mat_par, c->d_bg, c->d_cmf, c->d_rng, c->d_fb, c->d_tiles, c->d_counters, c->d_tile_cost, c->d_tile_order, c->d_rowmajor};
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -224,8 +226,10 @@ int srt_render_chunk(srt_ctx *c, uint32_t width, uint32_t height, uint32_t offx,
     hipStream_t st = (hipStream_t)stream;
     width = (uint16_t)width; height = (uint16_t)height; offx = (uint16_t)offx; offy = (uint16_t)offy;   // rendering.cu:245 (Q17)
     c->last_w = width; c->last_h = height; c->last_offx = offx; c->last_offy = offy;
-    // tiles cover the pixels the reference grid can address
-    const uint32_t cover_w = std::min<uint32_t>(width, c->tx * c->bx), cover_h = std::min<uint32_t>(height, c->ty * c->by);
+    // Tiles cover every pixel the reference grid can address, whatever the size of THIS chunk: the tile number of a lane
+    // idx -- and with it the rank that owns the lane's persistent RNG stream (Q13) -- must not move when a ragged edge
+    // chunk is narrower than the one before.  Tiles (partly) outside the chunk just skip those pixels (rendering.cu:205).
+    const uint32_t cover_w = c->tx * c->bx, cover_h = c->ty * c->by;
     c->tiles_x = (cover_w + 7) / 8; c->tiles_y = (cover_h + 7) / 8;
     c->n_tiles = c->tiles_x * c->tiles_y;
     c->tiles_padded = (c->n_tiles + c->world - 1) / c->world;
@@ -355,22 +359,26 @@ int srt_read_fb_rowmajor(srt_ctx *c, float *r, float *g, float *b, uint32_t imag
     if (!c || !c->d_fb || !r || !g || !b || image_width == 0 || image_height == 0) return fail(c, SRT_ERR_INVALID, "srt_read_fb_rowmajor: bad argument");
     HIP_TRY(c, hipSetDevice(c->device));
     const size_t n = (size_t)image_width * image_height;
-    float *tmp = nullptr;
-    HIP_TRY(c, hipMalloc((void **)&tmp, 3 * n * sizeof(float)));
-    hipError_t e = hipMemset(tmp, 0, 3 * n * sizeof(float));
-    // seed the staging image with the caller's current content so that chunks accumulate like update_fb does
-    if (e == hipSuccess) e = hipMemcpy(tmp, r, n * sizeof(float), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(tmp + n, g, n * sizeof(float), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(tmp + 2 * n, b, n * sizeof(float), hipMemcpyHostToDevice);
+    // context-owned row-major staging image: the un-swizzle writes the chunk's pixels into it on the device and only the
+    // chunk's rectangle travels to the caller's planes (update_fb touches nothing else either, render_manager.cuh:68-142)
+    if (c->rowmajor_w != image_width || c->rowmajor_h != image_height || !c->d_rowmajor) {
+        if (c->d_rowmajor) { (void)hipFree(c->d_rowmajor); c->d_rowmajor = nullptr; }
+        HIP_TRY(c, hipMalloc((void **)&c->d_rowmajor, 3 * n * sizeof(float)));
+        HIP_TRY(c, hipMemset(c->d_rowmajor, 0, 3 * n * sizeof(float)));
+        c->rowmajor_w = image_width; c->rowmajor_h = image_height;
+    }
     const float *src[3] = {c->d_fb, c->d_fb + (size_t)c->n_lanes, c->d_fb + 2 * (size_t)c->n_lanes};
-    float *dst[3] = {tmp, tmp + n, tmp + 2 * n};
-    if (e == hipSuccess) e = launch_unswizzle(src, dst, c->tx, c->ty, c->bx, c->by, c->last_w, c->last_h, c->last_offx, c->last_offy, image_width, image_height, nullptr);
-    if (e == hipSuccess) e = hipDeviceSynchronize();
-    if (e == hipSuccess) e = hipMemcpy(r, tmp, n * sizeof(float), hipMemcpyDeviceToHost);
-    if (e == hipSuccess) e = hipMemcpy(g, tmp + n, n * sizeof(float), hipMemcpyDeviceToHost);
-    if (e == hipSuccess) e = hipMemcpy(b, tmp + 2 * n, n * sizeof(float), hipMemcpyDeviceToHost);
-    (void)hipFree(tmp);
-    if (e != hipSuccess) return hip_fail(c, e, "srt_read_fb_rowmajor");
+    float *dst[3] = {c->d_rowmajor, c->d_rowmajor + n, c->d_rowmajor + 2 * n};
+    HIP_TRY(c, launch_unswizzle(src, dst, c->tx, c->ty, c->bx, c->by, c->last_w, c->last_h, c->last_offx, c->last_offy, image_width, image_height, nullptr));
+    if (c->last_offx < image_width && c->last_offy < image_height) {
+        const uint32_t w = std::min<uint32_t>(std::min<uint32_t>(c->last_w, c->tx * c->bx), image_width - c->last_offx);
+        const uint32_t h = std::min<uint32_t>(std::min<uint32_t>(c->last_h, c->ty * c->by), image_height - c->last_offy);
+        const size_t first = (size_t)c->last_offy * image_width + c->last_offx, pitch = (size_t)image_width * sizeof(float);
+        float *host[3] = {r, g, b};
+        for (int k = 0; k < 3 && w && h; k++)
+            HIP_TRY(c, hipMemcpy2D(host[k] + first, pitch, dst[k] + first, pitch, (size_t)w * sizeof(float), h, hipMemcpyDeviceToHost));
+    }
+    HIP_TRY(c, hipDeviceSynchronize());
     return SRT_OK;
 }
 
@@ -450,6 +458,41 @@ int srt_device_op_sweep(srt_ctx *c, int which, const float *a, const float *b, s
     if (e == hipSuccess) e = hipMemcpy(out, d + 2 * n, n * sizeof(float), hipMemcpyDeviceToHost);
     (void)hipFree(d);
     if (e != hipSuccess) return hip_fail(c, e, "srt_device_op_sweep");
+    return SRT_OK;
+}
+
+int srt_calibrate(srt_ctx *c, int kind, uint32_t waves_per_simd, uint32_t iters, srt_calibration *out) {
+    if (!c || !out || kind < 0 || kind >= calib_kinds() || waves_per_simd < 1 || waves_per_simd > 4 || iters == 0)
+        return fail(c, SRT_ERR_INVALID, "srt_calibrate: bad argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const uint32_t threads = waves_per_simd * 256u, n_blocks = (uint32_t)c->n_cu, n_waves = n_blocks * threads / 64u;
+    unsigned long long *d_cyc = nullptr;
+    float *d_sink = nullptr;
+    HIP_TRY(c, hipMalloc((void **)&d_cyc, n_waves * sizeof(unsigned long long)));
+    hipError_t e = hipMalloc((void **)&d_sink, 1024 * sizeof(float));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (e == hipSuccess) e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    if (e == hipSuccess) e = launch_calib(kind, n_blocks, threads, iters / 8u + 1u, d_sink, d_cyc, nullptr);   // warm-up (clocks, code)
+    if (e == hipSuccess) e = hipEventRecord(e0, nullptr);
+    if (e == hipSuccess) e = launch_calib(kind, n_blocks, threads, iters, d_sink, d_cyc, nullptr);
+    if (e == hipSuccess) e = hipEventRecord(e1, nullptr);
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    std::vector<unsigned long long> h(n_waves);
+    if (e == hipSuccess) e = hipMemcpy(h.data(), d_cyc, n_waves * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipFree(d_cyc);
+    if (d_sink) (void)hipFree(d_sink);
+    if (e != hipSuccess) return hip_fail(c, e, "srt_calibrate");
+    double sum = 0, mx = 0;
+    for (unsigned long long v : h) { sum += (double)v; mx = std::max(mx, (double)v); }
+    memset(out, 0, sizeof(*out));
+    out->wave_cycles_mean = sum / n_waves; out->wave_cycles_max = mx; out->wall_ms = ms;
+    out->instr_per_wave = (uint64_t)iters * 32u;
+    out->n_waves = n_waves; out->n_cu = n_blocks; out->waves_per_simd = waves_per_simd;
     return SRT_OK;
 }
 

@@ -1,0 +1,271 @@
+// srt_comm.cpp -- multi-GPU fan-out of the render path behind the C-ABI.
+//
+// The reference renders one chunk at a time on one GPU (render_manager::step, rendering/render_manager.cu:3-66).  Here a
+// frame (or chunk) is cut into 8x8-pixel tiles, rank r of W renders the tiles t with t % W == r (srt_set_partition), and
+// the only exchange is ONE gather of the compact tile buffers to rank 0 over RCCL (xGMI inside a node), followed by one
+// scatter kernel into rank 0's block-linear framebuffer.  Pixels are independent given the per-pixel seed
+// 1984 + block-linear idx (rendering.cu:137), so the image is bit-identical for any W.
+//
+// Two ways to form a communicator:
+//   srt_comm_init_all(devices, n)     one process drives n GPUs (ncclCommInitAll, one HIP stream per device)
+//   srt_comm_init_rank(ctx, id, r, W) one process per GPU (torch.distributed.run / mpirun); the id comes from
+//                                     srt_comm_unique_id on rank 0 and travels by whatever channel the launcher has
+// RCCL is loaded with dlopen on first use: a single-GPU user of libsrt_hip.so never loads it, and a host process that
+// carries its own RCCL copy (PyTorch does) is not disturbed.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <string.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "srt_host.h"
+#include "srt_internal.h"
+
+using namespace srt;
+
+namespace {
+
+struct RcclApi {
+    void *handle = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGather) Gather = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    std::string error;
+};
+
+RcclApi &rccl() {
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char *n : names) {
+            api.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+            if (api.handle) break;
+        }
+        if (!api.handle) { api.error = std::string("cannot load RCCL: ") + (dlerror() ? dlerror() : "librccl.so.1 not found"); return; }
+        bool ok = true;
+        auto sym = [&](const char *name) { void *p = dlsym(api.handle, name); if (!p) { ok = false; api.error = std::string("RCCL symbol missing: ") + name; } return p; };
+        api.GetUniqueId = (decltype(api.GetUniqueId))sym("ncclGetUniqueId");
+        api.CommInitRank = (decltype(api.CommInitRank))sym("ncclCommInitRank");
+        api.CommInitAll = (decltype(api.CommInitAll))sym("ncclCommInitAll");
+        api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy");
+        api.Gather = (decltype(api.Gather))sym("ncclGather");
+        api.GroupStart = (decltype(api.GroupStart))sym("ncclGroupStart");
+        api.GroupEnd = (decltype(api.GroupEnd))sym("ncclGroupEnd");
+        api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
+        if (!ok) { dlclose(api.handle); api.handle = nullptr; }
+    });
+    return api;
+}
+
+}  // namespace
+
+struct srt_comm {
+    uint32_t world = 1;
+    std::vector<srt_ctx *> ctx;        // local contexts
+    std::vector<uint32_t> rank;        // their global ranks
+    std::vector<ncclComm_t> nccl;
+    std::vector<hipStream_t> stream;   // one per local context
+    bool owns_ctx = false;
+    int root_local = -1;               // index of global rank 0 among the local contexts, -1 if it lives elsewhere
+    float *d_gathered = nullptr;       // on rank 0's device: world * tiles_padded * 9 * 64 floats, rank-major
+    size_t gathered_capacity = 0;
+    std::string err;
+};
+
+namespace {
+
+int cfail(srt_comm *c, int code, const std::string &msg) {
+    if (c) c->err = msg;
+    set_global_error(msg);
+    return code;
+}
+#define COMM_HIP(c, expr)                                                                         \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess) return cfail(c, SRT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+#define COMM_NCCL(c, expr)                                                                        \
+    do {                                                                                          \
+        ncclResult_t _r = (expr);                                                                 \
+        if (_r != ncclSuccess) return cfail(c, SRT_ERR_HIP, std::string(#expr) + ": " + rccl().GetErrorString(_r)); \
+    } while (0)
+
+int device_of(srt_ctx *ctx) { return srt_ctx_device(ctx); }
+
+}  // namespace
+
+extern "C" {
+
+int srt_comm_unique_id(unsigned char id[SRT_COMM_ID_BYTES]) {
+    static_assert(SRT_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "id size");
+    if (!id) return cfail(nullptr, SRT_ERR_INVALID, "srt_comm_unique_id: null id");
+    RcclApi &R = rccl();
+    if (!R.handle) return cfail(nullptr, SRT_ERR_UNSUPPORTED, "srt_comm_unique_id: " + R.error);
+    ncclUniqueId u;
+    COMM_NCCL(nullptr, R.GetUniqueId(&u));
+    memcpy(id, u.internal, NCCL_UNIQUE_ID_BYTES);
+    return SRT_OK;
+}
+
+int srt_comm_init_rank(srt_ctx *ctx, const unsigned char id[SRT_COMM_ID_BYTES], uint32_t rank, uint32_t world, srt_comm **out) {
+    if (!ctx || !id || !out || world == 0 || rank >= world) return cfail(nullptr, SRT_ERR_INVALID, "srt_comm_init_rank: bad argument");
+    *out = nullptr;
+    RcclApi &R = rccl();
+    if (!R.handle) return cfail(nullptr, SRT_ERR_UNSUPPORTED, "srt_comm_init_rank: " + R.error);
+    COMM_HIP(nullptr, hipSetDevice(device_of(ctx)));
+    srt_comm *c = new srt_comm();
+    c->world = world; c->ctx = {ctx}; c->rank = {rank}; c->owns_ctx = false; c->root_local = rank == 0 ? 0 : -1;
+    c->nccl.assign(1, nullptr); c->stream.assign(1, nullptr);
+    ncclUniqueId u;
+    memcpy(u.internal, id, NCCL_UNIQUE_ID_BYTES);
+    ncclResult_t r = R.CommInitRank(&c->nccl[0], (int)world, u, (int)rank);
+    if (r != ncclSuccess) { int rc = cfail(nullptr, SRT_ERR_HIP, std::string("ncclCommInitRank: ") + R.GetErrorString(r)); delete c; return rc; }
+    hipError_t e = hipStreamCreateWithFlags(&c->stream[0], hipStreamNonBlocking);
+    if (e != hipSuccess) { int rc = cfail(nullptr, SRT_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e)); srt_comm_destroy(c); return rc; }
+    int rc = srt_set_partition(ctx, rank, world);
+    if (rc != SRT_OK) { srt_comm_destroy(c); return rc; }
+    *out = c;
+    return SRT_OK;
+}
+
+int srt_comm_init_all(const int *devices, int n, srt_comm **out) {
+    if (!devices || n <= 0 || !out) return cfail(nullptr, SRT_ERR_INVALID, "srt_comm_init_all: bad argument");
+    *out = nullptr;
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < i; j++)
+            if (devices[i] == devices[j]) return cfail(nullptr, SRT_ERR_INVALID, "srt_comm_init_all: a device is listed twice (one rank per GPU)");
+    RcclApi &R = rccl();
+    if (!R.handle) return cfail(nullptr, SRT_ERR_UNSUPPORTED, "srt_comm_init_all: " + R.error);
+    srt_comm *c = new srt_comm();
+    c->world = (uint32_t)n; c->owns_ctx = true; c->root_local = 0;
+    c->ctx.assign(n, nullptr); c->rank.resize(n); c->nccl.assign(n, nullptr); c->stream.assign(n, nullptr);
+    for (int i = 0; i < n; i++) {
+        c->rank[i] = (uint32_t)i;
+        int rc = srt_create(devices[i], &c->ctx[i]);
+        if (rc == SRT_OK) rc = srt_set_partition(c->ctx[i], (uint32_t)i, (uint32_t)n);
+        if (rc == SRT_OK && hipStreamCreateWithFlags(&c->stream[i], hipStreamNonBlocking) != hipSuccess) rc = cfail(nullptr, SRT_ERR_HIP, "srt_comm_init_all: hipStreamCreate failed");
+        if (rc != SRT_OK) { srt_comm_destroy(c); return rc; }
+    }
+    ncclResult_t r = R.CommInitAll(c->nccl.data(), n, devices);
+    if (r != ncclSuccess) { int rc = cfail(nullptr, SRT_ERR_HIP, std::string("ncclCommInitAll: ") + R.GetErrorString(r)); srt_comm_destroy(c); return rc; }
+    *out = c;
+    return SRT_OK;
+}
+
+void srt_comm_destroy(srt_comm *c) {
+    if (!c) return;
+    RcclApi &R = rccl();
+    for (size_t i = 0; i < c->ctx.size(); i++) {
+        if (c->ctx[i]) { (void)hipSetDevice(device_of(c->ctx[i])); (void)hipDeviceSynchronize(); }
+        if (c->nccl[i] && R.handle) (void)R.CommDestroy(c->nccl[i]);
+        if (c->stream[i]) (void)hipStreamDestroy(c->stream[i]);
+    }
+    if (c->d_gathered && c->root_local >= 0) { (void)hipSetDevice(device_of(c->ctx[c->root_local])); (void)hipFree(c->d_gathered); }
+    if (c->owns_ctx) for (srt_ctx *x : c->ctx) if (x) srt_destroy(x);
+    delete c;
+}
+
+const char *srt_comm_last_error(const srt_comm *c) { return c ? c->err.c_str() : global_error(); }
+uint32_t srt_comm_world(const srt_comm *c) { return c ? c->world : 0; }
+uint32_t srt_comm_local_count(const srt_comm *c) { return c ? (uint32_t)c->ctx.size() : 0; }
+srt_ctx *srt_comm_ctx(srt_comm *c, uint32_t local_index) { return (c && local_index < c->ctx.size()) ? c->ctx[local_index] : nullptr; }
+srt_ctx *srt_comm_root_ctx(srt_comm *c) { return (c && c->root_local >= 0) ? c->ctx[c->root_local] : nullptr; }
+
+int srt_comm_upload_scene(srt_comm *c, const srt_scene *s) {
+    if (!c || !s) return cfail(c, SRT_ERR_INVALID, "srt_comm_upload_scene: null argument");
+    for (srt_ctx *x : c->ctx) { int rc = srt_upload_scene(x, s); if (rc != SRT_OK) return cfail(c, rc, srt_last_error(x)); }
+    return SRT_OK;
+}
+int srt_comm_set_camera(srt_comm *c, const srt_camera_data *cam) {
+    if (!c || !cam) return cfail(c, SRT_ERR_INVALID, "srt_comm_set_camera: null argument");
+    for (srt_ctx *x : c->ctx) { int rc = srt_set_camera(x, cam); if (rc != SRT_OK) return cfail(c, rc, srt_last_error(x)); }
+    return SRT_OK;
+}
+int srt_comm_init_device_params(srt_comm *c, uint32_t tx, uint32_t ty, uint32_t bx, uint32_t by, uint32_t chunk_w, uint32_t chunk_h,
+                                uint32_t spp, uint32_t bounce_limit, uint64_t seed) {
+    if (!c) return cfail(c, SRT_ERR_INVALID, "srt_comm_init_device_params: null comm");
+    for (srt_ctx *x : c->ctx) {
+        int rc = srt_init_device_params(x, tx, ty, bx, by, chunk_w, chunk_h, spp, bounce_limit, seed);
+        if (rc != SRT_OK) return cfail(c, rc, srt_last_error(x));
+    }
+    return SRT_OK;
+}
+
+// render_manager::step's device half for W GPUs: every local rank renders its tiles on its own stream, ONE gather brings
+// the compact tile buffers to rank 0, rank 0 scatters them into its block-linear framebuffer.  Asynchronous: returns once
+// everything is enqueued; srt_comm_synchronize waits.
+int srt_render_frame_multi(srt_comm *c, uint32_t width, uint32_t height, uint32_t offx, uint32_t offy) {
+    if (!c) return cfail(c, SRT_ERR_INVALID, "srt_render_frame_multi: null comm");
+    RcclApi &R = rccl();
+    const size_t n_local = c->ctx.size();
+    for (size_t i = 0; i < n_local; i++) {
+        int rc = srt_render_chunk(c->ctx[i], width, height, offx, offy, c->stream[i]);
+        if (rc != SRT_OK) return cfail(c, rc, srt_last_error(c->ctx[i]));
+    }
+    // every rank's buffer has the same size: tiles_padded * 9 * 64 floats
+    void *tiles0 = nullptr; size_t n_floats = 0; uint32_t tl = 0, tp = 0;
+    int rc = srt_tile_buffer(c->ctx[0], &tiles0, &n_floats, &tl, &tp);
+    if (rc != SRT_OK) return cfail(c, rc, srt_last_error(c->ctx[0]));
+    if (c->world == 1) {
+        rc = srt_scatter_tiles(c->ctx[0], nullptr, c->stream[0]);
+        return rc == SRT_OK ? SRT_OK : cfail(c, rc, srt_last_error(c->ctx[0]));
+    }
+    if (c->root_local >= 0 && (size_t)c->world * n_floats > c->gathered_capacity) {
+        COMM_HIP(c, hipSetDevice(device_of(c->ctx[c->root_local])));
+        COMM_HIP(c, hipStreamSynchronize(c->stream[c->root_local]));   // a scatter of the previous frame may still read it
+        if (c->d_gathered) { (void)hipFree(c->d_gathered); c->d_gathered = nullptr; c->gathered_capacity = 0; }
+        COMM_HIP(c, hipMalloc((void **)&c->d_gathered, (size_t)c->world * n_floats * sizeof(float)));
+        c->gathered_capacity = (size_t)c->world * n_floats;
+    }
+    COMM_NCCL(c, R.GroupStart());
+    for (size_t i = 0; i < n_local; i++) {
+        void *tiles = nullptr; size_t nf = 0;
+        rc = srt_tile_buffer(c->ctx[i], &tiles, &nf, nullptr, nullptr);
+        if (rc != SRT_OK || nf != n_floats) { (void)R.GroupEnd(); return cfail(c, SRT_ERR_INVALID, "srt_render_frame_multi: tile buffers of the ranks differ in size"); }
+        ncclResult_t r = R.Gather(tiles, (int)i == c->root_local ? c->d_gathered : nullptr, n_floats, ncclFloat, 0, c->nccl[i], c->stream[i]);
+        if (r != ncclSuccess) { (void)R.GroupEnd(); return cfail(c, SRT_ERR_HIP, std::string("ncclGather: ") + R.GetErrorString(r)); }
+    }
+    COMM_NCCL(c, R.GroupEnd());
+    if (c->root_local >= 0) {
+        rc = srt_scatter_tiles(c->ctx[c->root_local], c->d_gathered, c->stream[c->root_local]);
+        if (rc != SRT_OK) return cfail(c, rc, srt_last_error(c->ctx[c->root_local]));
+    }
+    return SRT_OK;
+}
+
+int srt_comm_synchronize(srt_comm *c) {
+    if (!c) return cfail(c, SRT_ERR_INVALID, "srt_comm_synchronize: null comm");
+    for (size_t i = 0; i < c->ctx.size(); i++) {
+        COMM_HIP(c, hipSetDevice(device_of(c->ctx[i])));
+        COMM_HIP(c, hipStreamSynchronize(c->stream[i]));
+    }
+    return SRT_OK;
+}
+
+// closest-hit queries of the last frame over the local ranks, and the slowest local render kernel (ms)
+int srt_comm_stats(srt_comm *c, uint64_t *rays, uint64_t *paths, float *max_kernel_ms) {
+    if (!c) return cfail(c, SRT_ERR_INVALID, "srt_comm_stats: null comm");
+    uint64_t r = 0, p = 0; float ms = 0.f;
+    for (srt_ctx *x : c->ctx) {
+        srt_stats st; float k = 0.f;
+        int rc = srt_get_stats(x, &st);
+        if (rc == SRT_OK) rc = srt_last_kernel_ms(x, &k);
+        if (rc != SRT_OK) return cfail(c, rc, srt_last_error(x));
+        r += st.rays; p += st.paths; ms = k > ms ? k : ms;
+    }
+    if (rays) *rays = r;
+    if (paths) *paths = p;
+    if (max_kernel_ms) *max_kernel_ms = ms;
+    return SRT_OK;
+}
+
+}  // extern "C"

@@ -73,6 +73,8 @@ hipError_t launch_unswizzle(const float *const src[3], float *const dst[3], uint
                             uint32_t image_height, hipStream_t st);
 hipError_t launch_trace(const RenderParams &p, const float *rays, size_t n, float *out, hipStream_t st);
 hipError_t launch_op_sweep(int which, const float *a, const float *b, size_t n, float *out, hipStream_t st);
+hipError_t launch_calib(int kind, uint32_t n_blocks, uint32_t threads, uint32_t iters, float *sink, unsigned long long *cycles, hipStream_t st);
+int calib_kinds();
 size_t render_lds_bytes(int stack_depth, int waves_per_block, int n_cached, int n_records);
 void render_launch_shape(int stack_depth, int n_records, int n_inner, int &waves_per_block, int &n_cached);
 

@@ -347,8 +347,10 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
                         // queue row = tile | part << 22 | s << 28: the row covers lanes [part * (64 >> s), (part + 1) * (64 >> s))
                         // of the tile (s = 0: the whole tile).  Cost-descending order, see order_tiles_kernel.
                         const uint32_t *tile_order = join_ptr<const uint32_t>(U->tile_order[0], U->tile_order[1]);
-                        const uint32_t row = tile_order ? tile_order[pix >> 6] : (pix >> 6);
-                        const uint32_t tile_local = row & 0x3fffffu, row_part = (row >> 22) & 63u, row_s = (row >> 28) & 7u;
+                        // (no ordered queue: the row IS the local tile, whatever its magnitude -- nothing to decode)
+                        const uint32_t row = tile_order ? tile_order[pix >> 6] : 0u;
+                        const uint32_t tile_local = tile_order ? (row & 0x3fffffu) : (pix >> 6);
+                        const uint32_t row_part = (row >> 22) & 63u, row_s = (row >> 28) & 7u;
                         const uint32_t lt = pix & 63u;
                         // A split row is meant for a wave that takes it whole (all 64 lanes fetch together: first fill, or
                         // after an exclusive row).  Then the lanes outside the row's share park.  A lane that refills on its own
@@ -469,7 +471,7 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
                 const uint32_t s_fr = (uint32_t)__popcll(fringe_mask) * P.score_fringe;
                 const uint32_t s_in = (uint32_t)__popcll(trav_mask & ~fringe_mask) << 8;
                 if (s_sh > s_fr && s_sh > s_in) break;
-                do_fringe = s_fr > s_in;
+                do_fringe = s_fr > s_in || fringe_mask == trav_mask;   // (every traversing lane at a fringe record: always progress)
             } else {
                 if (__popcll(alive_mask & ~trav_mask) >= shade_thr) break;
                 do_fringe = (__popcll(fringe_mask) >= fringe_thr) || (fringe_mask == trav_mask);
@@ -749,10 +751,11 @@ static hipError_t launch_render_mode(const RenderParams &p_in, uint32_t n_cu, hi
     }
     p.n_cached = n_cached;
     const size_t lds = render_lds_bytes(p.stack_depth, wpb, n_cached, p.n_records);
-    static bool attr_set = false;   // one flag per template instance
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<MODE, NARROW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget);
-        attr_set = true;
+    // per launch, not once per process: the attribute belongs to the function ON THE CURRENT DEVICE, and one process may
+    // drive several GPUs (srt_comm_init_all); the call is a host-side table update
+    {
+        const hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<MODE, NARROW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget);
+        if (ae != hipSuccess) return ae;
     }
     // persistent waves: fill every CU (16 waves per CU at this kernel's register budget), never more waves than tiles
     uint32_t waves_per_cu = p.waves_per_cu_override > 0 ? p.waves_per_cu_override : 16u;

@@ -115,6 +115,18 @@ class Renderer:
         self._ck(B.lib().srt_last_kernel_ms(self._h, C.byref(ms)))
         return ms.value
 
+    def calibrate(self, kind, waves_per_simd=4, iters=20000):
+        """Issue-rate microkernel (csrc/srt_calib.hip).  Returns per-SIMD instructions per cycle and the chip-wide rate."""
+        cal = B.Calibration()
+        self._ck(B.lib().srt_calibrate(self._h, kind, waves_per_simd, iters, C.byref(cal)))
+        n_simd = cal.n_cu * 4
+        total = cal.instr_per_wave * cal.n_waves
+        return dict(kind=kind, waves_per_simd=cal.waves_per_simd, n_cu=cal.n_cu, wave_cycles_mean=cal.wave_cycles_mean,
+                    wave_cycles_max=cal.wave_cycles_max, wall_ms=cal.wall_ms, instr_per_wave=cal.instr_per_wave,
+                    instr_per_cycle_per_simd=cal.instr_per_wave * cal.waves_per_simd / cal.wave_cycles_mean,
+                    instr_per_s=total / (cal.wall_ms * 1e-3), clock_ghz=cal.wave_cycles_max / (cal.wall_ms * 1e-3) / 1e9,
+                    n_simd=n_simd)
+
     def trace_rays(self, rays):
         rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
         out = np.zeros((rays.shape[0], 4), np.float32)

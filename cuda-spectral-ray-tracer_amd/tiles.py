@@ -15,8 +15,11 @@ LANES = 64
 
 
 def tile_geometry(width, height, tx, ty, bx, by, world):
+    """Tiles cover the whole reference grid (tx*bx x ty*by pixels), NOT just the current chunk: the tile number of a pixel --
+    and so the rank that owns its persistent RNG stream -- is the same for every chunk of a render (srt_render_chunk).
+    cover_w / cover_h are the pixels of the chunk that exist."""
     cover_w, cover_h = min(width, tx * bx), min(height, ty * by)
-    tiles_x, tiles_y = (cover_w + TILE - 1) // TILE, (cover_h + TILE - 1) // TILE
+    tiles_x, tiles_y = (tx * bx + TILE - 1) // TILE, (ty * by + TILE - 1) // TILE
     n_tiles = tiles_x * tiles_y
     return dict(tiles_x=tiles_x, tiles_y=tiles_y, n_tiles=n_tiles, tiles_padded=(n_tiles + world - 1) // world,
                 cover_w=cover_w, cover_h=cover_h)

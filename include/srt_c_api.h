@@ -209,6 +209,19 @@ SRT_API int srt_trace_rays(srt_ctx *ctx, const float *rays, size_t n, float *out
  * sweep"); used to prove the device's + - * / sqrt fmin cast and srt_powf bits equal the host's. */
 SRT_API int srt_device_op_sweep(srt_ctx *ctx, int which, const float *a, const float *b, size_t n, float *out);
 
+/* Issue-rate calibration (no reference counterpart: measurement support for bench.py's roofline).  Runs microkernel
+ * `kind` (csrc/srt_calib.hip: 0 v_add_f32, 1 v_pk_mul_f32, 2 v_fma_f32, 3 dependent v_add_f32 chain, 4 s_add_u32,
+ * 5 v_add_f32 + s_add_u32 interleaved, 6 v_cmp + v_cndmask, 7 / 8 ds_read_b64 linear / random, 9 v_max3_f32,
+ * 10 v_add_f32 with 26 of 64 lanes enabled) with one workgroup of waves_per_simd * 256 threads on every CU. */
+typedef struct {
+    double wave_cycles_mean, wave_cycles_max;   /* s_memtime ticks (shader cycles) a wave spent in its loop */
+    double wall_ms;                             /* HIP events around the launch */
+    uint64_t instr_per_wave;                    /* instructions of the measured loop body per wave (loop control excluded) */
+    uint32_t n_waves, n_cu, waves_per_simd;
+    uint32_t reserved;
+} srt_calibration;
+SRT_API int srt_calibrate(srt_ctx *ctx, int kind, uint32_t waves_per_simd, uint32_t iters, srt_calibration *out);
+
 #ifdef __cplusplus
 }
 #endif

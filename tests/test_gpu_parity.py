@@ -170,6 +170,60 @@ def test_partition_invariance_and_chunks(srt, gpu, orc):
     gpu.set_partition(0, 1)
 
 
+def test_ragged_chunks_multi_rank_match_oracle(srt, orc):
+    """A chunked render (40x40 chunks of a 72x56 image: the edge chunks are narrower / shorter) split over 4 ranks.  Every rank
+    is its own context with its own persistent RNG states (Q13), so the tile -> rank map must not depend on the size of the
+    current chunk: a lane whose tile moved to another rank would continue from a stream that never advanced.  The image
+    must equal the oracle's single-renderer chunk walk (render_manager.cu:3-66) bit for bit."""
+    import ctypes as C
+    import torch
+    scene = srt.Scene.builtin(srt.SCENE_PRISM).build_bvh(srt.BVH_REFERENCE, 1984)
+    W, H, spp, depth, cw, ch, world = 72, 56, 5, 8, 40, 40, 4
+    cam = scene.default_camera(W, H)
+    bx, by = cw // 28 + 1, ch // 16 + 1
+    ranks = []
+    for rank in range(world):
+        r = srt.Renderer(0)
+        r.upload_scene(scene); r.set_camera(cam)
+        r.init_device_params(cw, ch, spp, depth, 1984)
+        r.set_partition(rank, world)
+        ranks.append(r)
+    osc = oracle_scene_for(orc, scene, 0)
+    n = 28 * 16 * bx * by
+    states = np.zeros(6 * n, np.uint32)
+    for idx in range(n):
+        s = orc.Rng()
+        orc.lib().orc_rng_init(1984 + idx, C.byref(s))
+        states[6 * idx: 6 * idx + 6] = [s.d] + list(s.v)
+    for oy in range(0, H, ch):
+        for ox in range(0, W, cw):
+            w, h = min(cw, W - ox), min(ch, H - oy)
+            parts = []
+            for r in ranks:
+                r.render_chunk(w, h, ox, oy)
+                r.synchronize()
+                _, n_floats, _, _ = r.tile_buffer()
+                staging = torch.empty(n_floats, dtype=torch.float32, device="cuda")
+                r.copy_tile_buffer(staging.data_ptr(), torch.cuda.current_stream().cuda_stream)
+                torch.cuda.synchronize()
+                parts.append(staging)
+            gathered = torch.cat(parts)
+            ranks[0].scatter_tiles(gathered.data_ptr())
+            ranks[0].synchronize()
+            want = osc.render(cam, w, h, spp, depth, bx=bx, by=by, offx=ox, offy=oy, states=states)
+            got_fb, got_xyz = ranks[0].read_fb(), ranks[0].read_fb_aux(2)
+            # lanes outside this chunk keep what an earlier chunk left in the framebuffer: compare the chunk's own lanes
+            lane = np.arange(n)
+            blk, t = lane // 448, lane % 448
+            x, y = 28 * (blk % bx) + t % 28, 16 * (blk // bx) + t // 28
+            inside = (x < w) & (y < h)
+            for c in range(3):
+                assert np.array_equal(bits(got_xyz[c][inside]), bits(want["xyz"][c][inside])), ("chunk", ox, oy, "xyz", c)
+                assert np.array_equal(got_fb[c][inside], want["fb"][c][inside]), ("chunk", ox, oy, "fb", c)
+    for r in ranks:
+        r.close()
+
+
 def test_queue_scheduling_does_not_change_results(srt, gpu, orc, monkeypatch):
     """The pixel queue (cost order, expensive tiles split over several waves with parked lanes) is pure scheduling: the
     framebuffer is bit-identical with splitting off, with the default policy and with the most aggressive policy, and for

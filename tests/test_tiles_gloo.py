@@ -75,7 +75,7 @@ def test_tile_geometry_and_ownership(srt):
     for (W, H, world) in [(1920, 1080, 8), (1280, 720, 3), (50, 37, 2), (8, 8, 4)]:
         bx, by = W // 28 + 1, H // 16 + 1
         g = tiles.tile_geometry(W, H, 28, 16, bx, by, world)
-        assert g["n_tiles"] == ((W + 7) // 8) * ((H + 7) // 8)
+        assert g["n_tiles"] == ((28 * bx + 7) // 8) * ((16 * by + 7) // 8)     # the whole reference grid, not the chunk
         owned = sorted(t for r in range(world) for t in tiles.local_tile_ids(g["n_tiles"], r, world))
         assert owned == list(range(g["n_tiles"]))                      # a partition: no tile twice, none missing
         sizes = [len(tiles.local_tile_ids(g["n_tiles"], r, world)) for r in range(world)]

@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Issue-rate calibration on the GPU box: runs every microkernel of csrc/srt_calib.hip at 1, 2 and 4 waves per SIMD
+(one workgroup per CU) and prints / writes one JSON document.  The v_add_f32 row at 4 waves per SIMD is the peak
+bench.py's roofline divides by (the render kernel runs 4 waves per SIMD)."""
+import argparse, importlib, json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+srt = importlib.import_module("cuda-spectral-ray-tracer_amd")
+NAMES = {0: "v_add_f32 x8 independent", 1: "v_pk_mul_f32 x8 independent", 2: "v_fma_f32 x8 independent", 3: "v_add_f32 dependent chain",
+         4: "s_add_u32 x8 independent", 5: "v_add_f32 + s_add_u32 interleaved (32 instr = 16 VALU + 16 SALU)", 6: "v_cmp_lt_f32 + v_cndmask_b32 pairs",
+         7: "ds_read_b64 lane-linear (+ lgkmcnt(0) per 8)", 8: "ds_read_b64 random 16 B records (+ lgkmcnt(0) per 8)", 9: "v_max3_f32 x8",
+         10: "v_add_f32 x8, 26 of 64 lanes enabled"}
+ap = argparse.ArgumentParser()
+ap.add_argument("--iters", type=int, default=40000)
+ap.add_argument("--out", default=None)
+a = ap.parse_args()
+r = srt.Renderer(0)
+rows = []
+for kind in range(11):
+    for w in (1, 2, 4):
+        res = r.calibrate(kind, w, a.iters)
+        res["name"] = NAMES[kind]
+        rows.append(res)
+        print("%-70s w/SIMD %d: %.4f instr/cycle/SIMD, %.1f G wave-instr/s chip, clock %.3f GHz, wall %.2f ms" %
+              (NAMES[kind], w, res["instr_per_cycle_per_simd"], res["instr_per_s"] / 1e9, res["clock_ghz"], res["wall_ms"]), flush=True)
+doc = {"device": "MI355X (gfx950)", "iters": a.iters, "rows": rows}
+if a.out:
+    os.makedirs(os.path.dirname(a.out), exist_ok=True)
+    json.dump(doc, open(a.out, "w"), indent=1)
