@@ -38,10 +38,9 @@ struct srt_ctx {
     size_t tiles_capacity = 0;      // floats
     unsigned long long *d_counters = nullptr;     // [kCounters] statistics + 1 word pixel-queue head behind them
     int n_cu = 256;
-    uint32_t fringe_threshold = 16;                    // env SRT_FRINGE_THRESHOLD
-    uint32_t shade_threshold = 40, waves_per_cu = 0;   // tuning knobs (env SRT_SHADE_THRESHOLD / SRT_WAVES_PER_CU)
+    uint32_t waves_per_cu = 0;                         // experiment knob (env SRT_WAVES_PER_CU)
     // step choice of a wave: serve the kind of work (shade / fringe / inner) with the most waiting lanes per unit of cost;
-    // weights = 256 / relative cost of the step (inner = 256).  SRT_SCORE_SHADE=0 selects the older threshold rule.
+    // weights = 256 / relative cost of the step (inner = 256).
     uint32_t score_shade = 70, score_fringe = 280;      // env SRT_SCORE_SHADE / SRT_SCORE_FRINGE
     uint32_t debug_lane_limit = 0;                     // env SRT_DEBUG_LANE_LIMIT (experiments: partial tiles)
     uint32_t split_load_pct = 145;                    // env SRT_SPLIT_LOAD: load factor (%) of the capacity constraint in order_tiles_kernel's split policy (0 = never split)
@@ -119,14 +118,12 @@ int srt_create(int device, srt_ctx **out) {
     if (e != hipSuccess) return hip_fail(nullptr, e, "hipSetDevice");
     srt_ctx *c = new srt_ctx();
     c->device = device;
-    if (const char *ev = getenv("SRT_SHADE_THRESHOLD")) c->shade_threshold = (uint32_t)std::max(1, atoi(ev));
     if (const char *ev = getenv("SRT_WAVES_PER_CU")) c->waves_per_cu = (uint32_t)std::max(0, atoi(ev));
     if (const char *ev = getenv("SRT_PROBE_SPP")) c->probe_spp = (uint32_t)std::max(0, atoi(ev));
-    if (const char *ev = getenv("SRT_SCORE_SHADE")) c->score_shade = (uint32_t)std::max(0, atoi(ev));
+    if (const char *ev = getenv("SRT_SCORE_SHADE")) c->score_shade = (uint32_t)std::max(1, atoi(ev));
     if (const char *ev = getenv("SRT_SCORE_FRINGE")) c->score_fringe = (uint32_t)std::max(1, atoi(ev));   // 0 would starve fringe lanes
     if (const char *ev = getenv("SRT_DEBUG_LANE_LIMIT")) c->debug_lane_limit = (uint32_t)std::max(0, atoi(ev));
     if (const char *ev = getenv("SRT_SPLIT_LOAD")) c->split_load_pct = (uint32_t)std::max(0, atoi(ev));
-    if (const char *ev = getenv("SRT_FRINGE_THRESHOLD")) c->fringe_threshold = (uint32_t)std::max(1, atoi(ev));
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->n_cu = prop.multiProcessorCount;
@@ -248,8 +245,6 @@ int srt_render_chunk(srt_ctx *c, uint32_t width, uint32_t height, uint32_t offx,
     p.tiles_x = c->tiles_x; p.tiles_y = c->tiles_y; p.n_tiles = c->n_tiles;
     p.tiles_local = c->tiles_local;
     p.pixel_counter = (uint32_t *)(c->d_counters + kCounters);
-    p.shade_threshold = c->shade_threshold;
-    p.fringe_threshold = c->fringe_threshold;
     p.waves_per_cu_override = c->waves_per_cu;
     p.score_shade = c->score_shade; p.score_fringe = c->score_fringe;
     // ---- cost-ordered pixel queue --------------------------------------------------------------------------------

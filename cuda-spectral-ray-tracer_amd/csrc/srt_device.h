@@ -213,13 +213,14 @@ struct TravStats {
 };
 
 struct Trav {
-    int node;        // >= 0: record to visit next; < 0: not traversing
+    int node;        // >= 0: record to visit next; kTravDone (-1): query finished, result not yet shaded; kTravIdle (-2): no query
     int sp;          // stack entries in use
-    int top;         // the newest stack entry lives in a register (valid iff sp > 0); LDS holds entries 0 .. sp-2
+    int top;         // the newest stack entry lives in a register; -1 when the stack is empty.  LDS holds entries 0 .. sp-2
     float c;         // closest_so_far
     int hit;         // triangle of the closest hit or -1
     uint32_t nf[3];  // LDS byte address of the near pair of inner record 0, per axis (see NodeSrc)
 };
+constexpr int kTravDone = -1, kTravIdle = -2;
 
 // Start a closest-hit query (bvh.cu:101-119).  Returns true when the query is already finished (leaf root).
 template <bool COUNT>
@@ -232,14 +233,14 @@ __device__ __forceinline__ bool trav_begin(Trav &tv, const float4 *__restrict__ 
     // without walking.  The instrumented build records the skipped query in ts.n_nan.
     if (d.x != d.x || d.y != d.y || d.z != d.z) {
         if (COUNT) ts.n_nan++;
-        tv.node = -1;
+        tv.node = kTravDone;
         return true;
     }
     if (root_ref < 0) {   // root is a leaf: only one element
         float t;
         if (COUNT) ts.n_tri++;
         if (tri_test(tris, ~root_ref, o, d, 0.0f, tv.c, t)) { tv.c = t; tv.hit = ~root_ref; }
-        tv.node = -1;
+        tv.node = kTravDone;
         return true;
     }
     tv.node = root_ref;
@@ -340,20 +341,20 @@ __device__ __forceinline__ void fetch_node(const NodeSrc &ns, int node, V3 inv, 
     }
 }
 
-// Traversal stack: this lane's column, element k at index k*64; 16-bit entries when every record index fits (NARROW).
+// Traversal stack: this lane's column of LDS slots, slot k at index k*64; 16-bit slots when every record index fits 15 bits
+// (NARROW).  Slots 0 and 1 are sentinels holding -1, entry k of the stack lives in slot k + 2.
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
 typedef __attribute__((address_space(3))) uint16_t lds_u16;
+typedef __attribute__((address_space(3))) int32_t lds_i32;
+typedef __attribute__((address_space(3))) int16_t lds_i16;
+constexpr int kStackSentinels = 2;
 struct StackRef {
-    lds_u32 *s32;      // used when !NARROW
-    lds_u16 *s16;      // used when NARROW
+    lds_i32 *s32;      // used when !NARROW
+    lds_i16 *s16;      // used when NARROW
 };
 template <bool NARROW>
-__device__ __forceinline__ void stack_push(const StackRef &st, int sp, int ref) {
-    if (NARROW) st.s16[sp * 64] = (uint16_t)ref; else st.s32[sp * 64] = (uint32_t)ref;
-}
-template <bool NARROW>
-__device__ __forceinline__ int stack_pop(const StackRef &st, int sp) {
-    return NARROW ? (int)st.s16[sp * 64] : (int)st.s32[sp * 64];
+__device__ __forceinline__ void stack_init(const StackRef &st) {
+    if (NARROW) { st.s16[0] = (int16_t)-1; st.s16[64] = (int16_t)-1; } else { st.s32[0] = -1; st.s32[64] = -1; }
 }
 
 // aabb::hit (bvh/aabb.cu:7-40) for both child boxes at once (x = left child, y = right child), packed fp32, with the
@@ -372,40 +373,57 @@ __device__ __forceinline__ void box_pair(const BoxPairs &b, V3 o, V3 inv, float 
 }
 
 // bvh.cu:154-160: pop when neither child is to be traversed; otherwise descend left first and push right iff both.
-// The newest entry is kept in a register: a pop hands it out immediately and re-fills the register with an LDS read
-// whose result is not needed before the NEXT pop or push, so the LDS latency leaves the critical path of the step.
+//
+// Branch-free (a divergent `if` costs three scalar instructions for the EXEC juggling, and scalar instructions take issue
+// slots like vector ones -- profiles/r02/calib_issue_rates.txt): the newest entry lives in the register `top` (-1 when the
+// stack is empty), LDS holds entries 0 .. sp-2.  Every step
+//   * reads `below` = entry sp-2 (slot sp; the two sentinel slots make that -1 for sp < 2) -- needed only by a pop, but an
+//     unconditional read issued before the box arithmetic is off the critical path and cheaper than a branch;
+//   * writes `top` to its LDS home, the slot of entry sp-1 -- needed only by a push, harmless otherwise (that slot is dead
+//     while the entry lives in the register; with sp = 0 it re-writes the sentinel -1).
+// Then  pop : node = top, top = below, sp-1      push : node = lref, top = rref, sp+1      else : node = the one child hit.
+// A pop from the empty stack yields node = top = -1 = kTravDone.
 template <bool NARROW>
-__device__ __forceinline__ void trav_advance(Trav &tv, bool trav_l, bool trav_r, int lref, int rref, const StackRef &stack) {
-    if (!trav_l && !trav_r) {
-        if (tv.sp == 0) tv.node = -1;
-        else {
-            tv.node = tv.top;
-            tv.sp--;
-            if (tv.sp > 0) tv.top = stack_pop<NARROW>(stack, tv.sp - 1);
-        }
-    } else {
-        tv.node = trav_l ? lref : rref;
-        if (trav_l && trav_r) {
-            if (tv.sp > 0) stack_push<NARROW>(stack, tv.sp - 1, tv.top);
-            tv.top = rref;
-            tv.sp++;
-        }
-    }
+__device__ __forceinline__ int stack_exchange(const StackRef &st, int sp, int top) {
+    int below;
+    if (NARROW) { below = (int)st.s16[sp * 64]; st.s16[(sp + 1) * 64] = (int16_t)top; }
+    else { below = st.s32[sp * 64]; st.s32[(sp + 1) * 64] = top; }
+    return below;
+}
+__device__ __forceinline__ void trav_advance(Trav &tv, bool trav_l, bool trav_r, int lref, int rref, int below) {
+    const bool both = trav_l & trav_r, none = !(trav_l | trav_r);
+    const int top = tv.top;
+    tv.node = trav_l ? lref : (trav_r ? rref : top);
+    tv.top = both ? rref : (none ? below : top);
+    tv.sp = tv.sp + (both ? 1 : 0) - (none ? 1 : 0);
 }
 
-// Visit of an INNER record (both children internal): two box tests, no triangle work.
-template <bool COUNT, bool NARROW>
+// Visit of an INNER record (both children internal): two box tests, no triangle work.  ALL_CACHED: the whole inner tree is
+// LDS resident (n_cached == n_inner), no global fall-back path in the step.
+template <bool COUNT, bool NARROW, bool ALL_CACHED>
 __device__ __forceinline__ void trav_step_inner(Trav &tv, const NodeSrc &ns, V3 o, V3 inv, const StackRef &stack, TravStats &ts) {
     BoxPairs b;
     int lref, rref;
-    fetch_node<NARROW>(ns, tv.node, inv, tv.nf, b, lref, rref);
+    const int below = stack_exchange<NARROW>(stack, tv.sp, tv.top);
+    if (ALL_CACHED) {
+        const uint32_t node = (uint32_t)tv.node, rec = node << 4;
+        const uint32_t ax = rec + tv.nf[0], ay = rec + tv.nf[1], az = rec + tv.nf[2];
+        b.nx = *(lds_cf2 *)(uintptr_t)ax; b.fx = *(lds_cf2 *)(uintptr_t)(ax ^ 8u);
+        b.ny = *(lds_cf2 *)(uintptr_t)ay; b.fy = *(lds_cf2 *)(uintptr_t)(ay ^ 8u);
+        b.nz = *(lds_cf2 *)(uintptr_t)az; b.fz = *(lds_cf2 *)(uintptr_t)(az ^ 8u);
+        const uint32_t r0 = ns.lds_r0[node];
+        if (NARROW) { lref = (int)(r0 & 0xffffu); rref = (int)(r0 >> 16); }
+        else { lref = (int)r0; rref = (int)ns.lds_r1[node]; }
+    } else {
+        fetch_node<NARROW>(ns, tv.node, inv, tv.nf, b, lref, rref);
+    }
     if (COUNT) { ts.n_iters++; ts.n_box += 2u; }
     float e_l, m_l, e_r, m_r;
     box_pair(b, o, inv, e_l, m_l, e_r, m_r);
     const float c = tv.c;
     const bool trav_l = !(fminf(c, m_l) <= e_l);
     const bool trav_r = !(fminf(c, m_r) <= e_r);
-    trav_advance<NARROW>(tv, trav_l, trav_r, lref, rref, stack);
+    trav_advance(tv, trav_l, trav_r, lref, rref, below);
 }
 
 // Visit of a FRINGE record (at least one leaf child).
@@ -417,6 +435,7 @@ __device__ __forceinline__ void trav_step_fringe(Trav &tv, const NodeSrc &ns, V3
     const f4v hd = buf_load16(ns.global_fringe, off);
     const f4v al = buf_load16(ns.global_fringe, off + 16u), bl = buf_load16(ns.global_fringe, off + 32u), cl = buf_load16(ns.global_fringe, off + 48u);
     const f4v ar = buf_load16(ns.global_fringe, off + 64u), br = buf_load16(ns.global_fringe, off + 80u), cr = buf_load16(ns.global_fringe, off + 96u);
+    const int below = stack_exchange<NARROW>(stack, tv.sp, tv.top);
     const int lref = (int)__float_as_uint(hd.x), rref = (int)__float_as_uint(hd.y);
     const bool leaf_l = lref < 0, leaf_r = rref < 0;
     if (COUNT) { ts.n_iters++; ts.n_tri += (leaf_l ? 1u : 0u) + (leaf_r ? 1u : 0u); ts.n_box += (leaf_l ? 0u : 1u) + (leaf_r ? 0u : 1u); }
@@ -432,40 +451,38 @@ __device__ __forceinline__ void trav_step_fringe(Trav &tv, const NodeSrc &ns, V3
         box_pair(b, o, inv, e_l, m_l, e_r, m_r);
     }
 
-    // ---- both leaf triangles in one segment ------------------------------------------------------------------------
-    float t_l = 0.f, t_r = 0.f;
-    bool ok_l = false, ok_r = false;          // plane not parallel, t >= tmin, inside (everything but `t <= c`)
-    if (leaf_l || leaf_r) {
-        const f2 nx = mk2(al.x, ar.x), ny = mk2(al.y, ar.y), nz = mk2(al.z, ar.z), D = mk2(al.w, ar.w);
-        const f2 denom = nx * d.x + ny * d.y + nz * d.z;                      // dot(normal, dir), tri.cu:9
-        const f2 num = D - (nx * o.x + ny * o.y + nz * o.z);                  // D - dot(normal, origin), tri.cu:17
-        const f2 t = mk2(num.x / denom.x, num.y / denom.y);
-        const uint32_t fl = __float_as_uint(cl.z), fr = __float_as_uint(cr.z);
-        const bool wyl = fl & kTriWIsY, hzl = fl & kTriHIsZ, wyr = fr & kTriWIsY, hzr = fr & kTriHIsZ;
-        // intersection = orig + t*dir (ray.cuh:31-34), the two projected components
-        const f2 pw = mk2(wyl ? o.y : o.x, wyr ? o.y : o.x) + t * mk2(wyl ? d.y : d.x, wyr ? d.y : d.x);
-        const f2 ph = mk2(hzl ? o.z : o.y, hzr ? o.z : o.y) + t * mk2(hzl ? d.z : d.y, hzr ? d.z : d.y);
-        // double_signed_area_2D(v1,v2,v3) = (v1[w]-v3[w])*(v2[h]-v3[h]) - (v2[w]-v3[w])*(v1[h]-v3[h])   (tri.cu:181)
-        const f2 v0w = mk2(bl.x, br.x), v0h = mk2(bl.y, br.y), v1w = mk2(bl.z, br.z), v1h = mk2(bl.w, br.w), v2w = mk2(cl.x, cr.x), v2h = mk2(cl.y, cr.y);
-        const f2 a1 = (pw - v1w) * (v0h - v1h) - (v0w - v1w) * (ph - v1h);     // (p, v0, v1)
-        const f2 a2 = (pw - v2w) * (v1h - v2h) - (v1w - v2w) * (ph - v2h);     // (p, v1, v2)
-        const f2 a3 = (pw - v0w) * (v2h - v0h) - (v2w - v0w) * (ph - v0h);     // (p, v2, v0)
-        const bool in_l = (fl & kTriClockwise) ? (a1.x >= 0.f && a2.x >= 0.f && a3.x >= 0.f) : (a1.x <= 0.f && a2.x <= 0.f && a3.x <= 0.f);
-        const bool in_r = (fr & kTriClockwise) ? (a1.y >= 0.f && a2.y >= 0.f && a3.y >= 0.f) : (a1.y <= 0.f && a2.y <= 0.f && a3.y <= 0.f);
-        t_l = t.x; t_r = t.y;
-        ok_l = leaf_l && !(fabsf(denom.x) < 1e-8f) && (0.0f <= t.x) && in_l;
-        ok_r = leaf_r && !(fabsf(denom.y) < 1e-8f) && (0.0f <= t.y) && in_r;
-    }
+    // ---- both leaf triangles in one segment (a fringe record has at least one; the other side's values are ignored) -----
+    const f2 nx = mk2(al.x, ar.x), ny = mk2(al.y, ar.y), nz = mk2(al.z, ar.z), D = mk2(al.w, ar.w);
+    const f2 denom = nx * d.x + ny * d.y + nz * d.z;                      // dot(normal, dir), tri.cu:9
+    const f2 num = D - (nx * o.x + ny * o.y + nz * o.z);                  // D - dot(normal, origin), tri.cu:17
+    const f2 t = mk2(num.x / denom.x, num.y / denom.y);
+    const uint32_t fl = __float_as_uint(cl.z), fr = __float_as_uint(cr.z);
+    const bool wyl = fl & kTriWIsY, hzl = fl & kTriHIsZ, wyr = fr & kTriWIsY, hzr = fr & kTriHIsZ;
+    // intersection = orig + t*dir (ray.cuh:31-34), the two projected components
+    const f2 pw = mk2(wyl ? o.y : o.x, wyr ? o.y : o.x) + t * mk2(wyl ? d.y : d.x, wyr ? d.y : d.x);
+    const f2 ph = mk2(hzl ? o.z : o.y, hzr ? o.z : o.y) + t * mk2(hzl ? d.z : d.y, hzr ? d.z : d.y);
+    // double_signed_area_2D(v1,v2,v3) = (v1[w]-v3[w])*(v2[h]-v3[h]) - (v2[w]-v3[w])*(v1[h]-v3[h])   (tri.cu:181)
+    const f2 v0w = mk2(bl.x, br.x), v0h = mk2(bl.y, br.y), v1w = mk2(bl.z, br.z), v1h = mk2(bl.w, br.w), v2w = mk2(cl.x, cr.x), v2h = mk2(cl.y, cr.y);
+    const f2 a1 = (pw - v1w) * (v0h - v1h) - (v0w - v1w) * (ph - v1h);     // (p, v0, v1)
+    const f2 a2 = (pw - v2w) * (v1h - v2h) - (v1w - v2w) * (ph - v2h);     // (p, v1, v2)
+    const f2 a3 = (pw - v0w) * (v2h - v0h) - (v2w - v0w) * (ph - v0h);     // (p, v2, v0)
+    const bool in_l = (fl & kTriClockwise) ? (a1.x >= 0.f) & (a2.x >= 0.f) & (a3.x >= 0.f) : (a1.x <= 0.f) & (a2.x <= 0.f) & (a3.x <= 0.f);
+    const bool in_r = (fr & kTriClockwise) ? (a1.y >= 0.f) & (a2.y >= 0.f) & (a3.y >= 0.f) : (a1.y <= 0.f) & (a2.y <= 0.f) & (a3.y <= 0.f);
+    // plane not parallel, t >= tmin, inside (everything but `t <= c`)
+    const bool ok_l = leaf_l & !(fabsf(denom.x) < 1e-8f) & (0.0f <= t.x) & in_l;
+    const bool ok_r = leaf_r & !(fabsf(denom.y) < 1e-8f) & (0.0f <= t.y) & in_r;
 
-    // ---- decisions in the reference's order (bvh.cu:128-160) -------------------------------------------------------
-    float c = tv.c;
-    bool trav_l, trav_r;
-    if (leaf_l) { trav_l = false; if (ok_l && t_l <= c) { c = t_l; tv.hit = ~lref; } }
-    else trav_l = !(fminf(c, m_l) <= e_l);
-    if (leaf_r) { trav_r = false; if (ok_r && t_r <= c) { c = t_r; tv.hit = ~rref; } }
-    else trav_r = !(fminf(c, m_r) <= e_r);
-    tv.c = c;
-    trav_advance<NARROW>(tv, trav_l, trav_r, lref, rref, stack);
+    // ---- decisions in the reference's order (bvh.cu:128-160): left child with c, right child with the updated c -----------
+    const float c0 = tv.c;
+    const bool hit_l = ok_l & (t.x <= c0);
+    const float c1 = hit_l ? t.x : c0;
+    const bool trav_l = !leaf_l & !(fminf(c0, m_l) <= e_l);
+    const bool hit_r = ok_r & (t.y <= c1);
+    const float c2 = hit_r ? t.y : c1;
+    const bool trav_r = !leaf_r & !(fminf(c1, m_r) <= e_r);
+    tv.c = c2;
+    tv.hit = hit_r ? ~rref : (hit_l ? ~lref : tv.hit);
+    trav_advance(tv, trav_l, trav_r, lref, rref, below);
 }
 
 }  // namespace srt

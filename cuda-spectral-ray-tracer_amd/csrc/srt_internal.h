@@ -39,14 +39,12 @@ struct RenderParams {
     uint32_t rank, world;                 // this launch renders tiles t with t % world == rank
     uint32_t tiles_local;                 // number of tiles this rank owns (pixel queue length / 64)
     uint32_t *pixel_counter;              // device word, zeroed before the launch: head of the pixel queue
-    uint32_t shade_threshold;             // traversal phase yields to shading once this many lanes wait
-    uint32_t fringe_threshold;            // lanes at fringe records wait until this many of them can share a triangle step
     const uint32_t *tile_order;           // optional: queue slot -> local tile (cost-descending order); null = identity
     uint32_t *tile_cost;                  // probe mode: per local tile, node records visited by its pixels
     const uint32_t *queue_rows;           // optional: [0] = number of queue rows (device-written by order_tiles_kernel)
     uint32_t queue_rows_bound;            // host-side upper bound of the row count (= tiles_local without splitting)
     uint32_t waves_per_cu_override;       // 0 = occupancy API
-    uint32_t score_shade, score_fringe;   // step-choice weights, 256 / relative step cost (score_shade 0 = threshold rule)
+    uint32_t score_shade, score_fringe;   // step-choice weights, 256 / relative step cost (both >= 1)
     uint32_t debug_lane_limit;            // experiments only (env SRT_DEBUG_LANE_LIMIT): lanes >= limit of every tile stay idle
     // state / outputs
     uint32_t *rng;                        // SoA: 6 planes of n_lanes words, indexed by the block-linear idx

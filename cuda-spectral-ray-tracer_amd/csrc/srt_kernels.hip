@@ -44,9 +44,10 @@ __device__ __forceinline__ T *join_ptr(uint32_t lo, uint32_t hi) { return reinte
 
 constexpr size_t kLdsBudget = 160 * 1024;
 static inline size_t round16(size_t v) { return (v + 15) & ~(size_t)15; }
-static inline bool narrow_refs(int n_records) { return n_records <= 65535; }
+static inline bool narrow_refs(int n_records) { return n_records <= 32767; }   // 15 bits: a 16-bit stack slot also holds the sentinel -1
 static inline size_t cache_bytes(int n_cached, int n_records) { return round16((size_t)n_cached * (narrow_refs(n_records) ? 52 : 56)); }
-static inline size_t stack_bytes(int stack_depth, int n_records) { return (size_t)(stack_depth < 1 ? 1 : stack_depth) * 64 * (narrow_refs(n_records) ? 2 : 4); }
+static inline size_t stack_slots(int stack_depth) { return (size_t)(stack_depth < 1 ? 1 : stack_depth) + kStackSentinels; }
+static inline size_t stack_bytes(int stack_depth, int n_records) { return stack_slots(stack_depth) * 64 * (narrow_refs(n_records) ? 2 : 4); }
 size_t render_lds_bytes(int stack_depth, int waves_per_block, int n_cached, int n_records) {
     return (size_t)kLdsTablesF4 * 16 + cache_bytes(n_cached, n_records) + (size_t)waves_per_block * stack_bytes(stack_depth, n_records);
 }
@@ -94,7 +95,7 @@ __global__ void init_rng_kernel(uint32_t *rng, uint32_t n_lanes, uint64_t seed) 
 
 // One lane = a small state machine that owns one pixel at a time:
 //   TRAV   (tv.node >= 0)                 walking the BVH for its current ray
-//   RESULT (result_ready)                 traversal finished, hit record waits to be shaded
+//   RESULT (tv.node == kTravDone)         traversal finished, hit record waits to be shaded
 //   IDLE   (!have_path)                   needs a new camera ray, or a new pixel when its samples are used up
 //   DEAD                                  pixel queue drained
 //   PARKED                                split queue rows only: waits until the wave's expensive pixels are done
@@ -105,7 +106,8 @@ __global__ void init_rng_kernel(uint32_t *rng, uint32_t n_lanes, uint64_t seed) 
 // stream belongs to the pixel).
 // MODE 0: production; MODE 1: instrumented (counts V / T / utilisation); MODE 2: cost probe -- renders P.spp samples per
 // pixel from a COPY of the RNG state, writes nothing but the per-tile traversal cost used to order the pixel queue.
-template <int MODE, bool NARROW>
+// ALL_CACHED: the whole inner tree fits the LDS cache (n_cached == n_inner): the INNER step has no global fall-back path.
+template <int MODE, bool NARROW, bool ALL_CACHED>
 __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
     constexpr bool COUNT = (MODE == 1);
     constexpr bool PROBE = (MODE == 2);
@@ -156,13 +158,14 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
     const uint32_t spp = P.spp;
     StackRef my_stack;
     {
-        const size_t depth = (size_t)(P.stack_depth < 1 ? 1 : P.stack_depth);
-        my_stack.s16 = (lds_u16 *)(s_stack_base + (size_t)wave * depth * 128u) + lane;
-        my_stack.s32 = (lds_u32 *)(s_stack_base + (size_t)wave * depth * 256u) + lane;
+        const size_t slots = (size_t)(P.stack_depth < 1 ? 1 : P.stack_depth) + kStackSentinels;
+        my_stack.s16 = (lds_i16 *)(s_stack_base + (size_t)wave * slots * 128u) + lane;
+        my_stack.s32 = (lds_i32 *)(s_stack_base + (size_t)wave * slots * 256u) + lane;
+        stack_init<NARROW>(my_stack);      // this wave's own column: no barrier needed
     }
 
     // ---- lane state ---------------------------------------------------------------------------------------
-    bool dead = false, have_path = false, result_ready = false, have_pixel = false;
+    bool dead = false, have_path = false, have_pixel = false;
     uint32_t idx = 0;                       // block-linear index of the current pixel (RNG / framebuffer slot)
     uint32_t out_slot = 0;                  // tile_local * 576 + lane_in_tile
     uint32_t pixel_ij = 0;                  // chunk-relative column | row << 16 (both are 16-bit quantities, Q17)
@@ -174,7 +177,7 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
     float pw[kWavelengths];
 #pragma unroll
     for (int k = 0; k < kWavelengths; k++) pw[k] = 0.f;
-    Trav tv; tv.node = -1; tv.sp = 0; tv.top = -1; tv.c = kFltMax; tv.hit = -1; tv.nf[0] = tv.nf[1] = tv.nf[2] = 0u;
+    Trav tv; tv.node = kTravIdle; tv.sp = 0; tv.top = -1; tv.c = kFltMax; tv.hit = -1; tv.nf[0] = tv.nf[1] = tv.nf[2] = 0u;
     uint32_t n_rays = 0;
     TravStats ts;
     // Rows of an expensive tile that was split over several waves (see order_tiles_kernel) are exclusive: the lanes whose
@@ -197,8 +200,8 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
             float xyz_x = 0.0f, xyz_y = 0.0f, xyz_z = 0.0f;      // XYZ of a path that ends in this pass
 
             // ---- S1: shade a finished closest-hit query: one iteration of ray_bounce's loop (rendering.cu:22-36)
-            if (!dead && tv.node < 0 && result_ready) {
-                result_ready = false;
+            if (!dead && tv.node == kTravDone) {
+                tv.node = kTravIdle;
                 float wl[kWavelengths];
                 hero_expand(hero, wl);
                 // the spectrum this segment multiplies into the path: the background on a miss (rendering.cu:24-27), the hit
@@ -430,71 +433,61 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
                 n_rays++;
                 inv = mk(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);           // aabb.cu:17, hoisted out of the box test
                 ray_near_addresses(ns, inv, tv.nf);
-                if (trav_begin<ITERS>(tv, P.tris, P.root_ref, ro, rd, ts)) result_ready = true;
+                (void)trav_begin<ITERS>(tv, P.tris, P.root_ref, ro, rd, ts);   // a query that finishes at once leaves kTravDone
             }
         }
 
         if (COUNT) { const unsigned long long now = __builtin_amdgcn_s_memtime(); t_shade += now - t_mark; t_mark = now; }
         // =========================== traversal phase =========================================================
         // Two kinds of steps: INNER (record with two internal children: box tests only) and FRINGE (a leaf child:
-        // box + triangle tests, several times the cost).  Lanes that reach a fringe record wait until
-        // P.fringe_threshold of them can share one fringe step, or until no lane has inner work left.
+        // box + triangle tests, several times the cost).  A step serves the lanes that sit at that kind of record.
         if (__ballot(!dead) == 0ull) break;
         const unsigned long long alive_mask = __ballot(!dead && !parked);
         if (alive_mask == 0ull) continue;     // only parked lanes left: wake them up
-        // the batching thresholds are fractions of the lanes that currently own work: a wave in the tail of the launch
-        // (queue empty, most lanes retired) or one that hosts a split row must not wait for idle lanes that never come
-        const int n_alive = __popcll(alive_mask);
-        const int shade_thr = max(1, ((int)P.shade_threshold * n_alive) >> 6);
-        const int fringe_thr = max(1, ((int)P.fringe_threshold * n_alive) >> 6);
-        if (!COUNT && n_alive == 1) {
+        const uint32_t n_alive = (uint32_t)__popcll(alive_mask);
+        const uint32_t n_inner_u = (uint32_t)P.n_inner;
+        if (!COUNT && n_alive == 1u) {
             // A wave with ONE working lane (a single-pixel row of a split tile, or the tail of the launch) has nothing to
             // schedule: walk the ray to the end in a tight loop.  Such waves are latency chains -- every instruction of the
             // step-choice logic is on the critical path of the pixel that bounds a chain-bound launch.
             while (__ballot(tv.node >= 0) != 0ull) {
                 if (tv.node >= 0) {
-                    if (tv.node < P.n_inner) trav_step_inner<ITERS, NARROW>(tv, ns, ro, inv, my_stack, ts);
+                    if ((uint32_t)tv.node < n_inner_u) trav_step_inner<ITERS, NARROW, ALL_CACHED>(tv, ns, ro, inv, my_stack, ts);
                     else trav_step_fringe<ITERS, NARROW>(tv, ns, ro, rd, inv, my_stack, ts);
-                    if (tv.node < 0) result_ready = true;
                 }
             }
             continue;
         }
         for (;;) {
+            // Serve the kind of work with the most waiting lanes per unit of step cost (weights = 256 / relative cost of the
+            // step, srt_capi.cpp).  Traversing lanes are alive (a lane retires or parks only between queries), so the lanes
+            // waiting for a shading pass are n_alive - n_trav.
             const unsigned long long trav_mask = __ballot(tv.node >= 0);
             if (trav_mask == 0ull) break;
-            const unsigned long long fringe_mask = __ballot(tv.node >= P.n_inner);
-            bool do_fringe;
-            if (P.score_shade != 0u) {
-                // serve the kind of work with the most waiting lanes per unit of step cost (weights: srt_capi.cpp)
-                const uint32_t s_sh = (uint32_t)__popcll(alive_mask & ~trav_mask) * P.score_shade;
-                const uint32_t s_fr = (uint32_t)__popcll(fringe_mask) * P.score_fringe;
-                const uint32_t s_in = (uint32_t)__popcll(trav_mask & ~fringe_mask) << 8;
-                if (s_sh > s_fr && s_sh > s_in) break;
-                do_fringe = s_fr > s_in || fringe_mask == trav_mask;   // (every traversing lane at a fringe record: always progress)
-            } else {
-                if (__popcll(alive_mask & ~trav_mask) >= shade_thr) break;
-                do_fringe = (__popcll(fringe_mask) >= fringe_thr) || (fringe_mask == trav_mask);
-            }
-            if (COUNT) { ts.w_iters++; ts.w_alive += (uint32_t)__popcll(alive_mask); if (do_fringe) { ts.w_fringe++; ts.l_fringe += (uint32_t)__popcll(fringe_mask); } else ts.l_inner += (uint32_t)__popcll(trav_mask & ~fringe_mask); }
+            const unsigned long long fringe_mask = __ballot(tv.node >= (int)n_inner_u);
+            const uint32_t n_trav = (uint32_t)__popcll(trav_mask), n_fringe = (uint32_t)__popcll(fringe_mask);
+            const uint32_t s_sh = (n_alive - n_trav) * P.score_shade;
+            const uint32_t s_fr = n_fringe * P.score_fringe;
+            const uint32_t s_in = (n_trav - n_fringe) << 8;
+            if (s_sh > max(s_fr, s_in)) break;
+            const bool do_fringe = s_fr > s_in || n_fringe == n_trav;   // (every traversing lane at a fringe record: always progress)
+            if (COUNT) { ts.w_iters++; ts.w_alive += n_alive; if (do_fringe) { ts.w_fringe++; ts.l_fringe += n_fringe; } else ts.l_inner += n_trav - n_fringe; }
             if (do_fringe) {
-                if (tv.node >= P.n_inner) {
-                    trav_step_fringe<ITERS, NARROW>(tv, ns, ro, rd, inv, my_stack, ts);
-                    if (tv.node < 0) result_ready = true;
-                }
+                if (tv.node >= (int)n_inner_u) trav_step_fringe<ITERS, NARROW>(tv, ns, ro, rd, inv, my_stack, ts);
                 if (COUNT) { const unsigned long long now = __builtin_amdgcn_s_memtime(); t_fringe += now - t_mark; t_mark = now; }
             } else {
                 // a short burst of inner steps between two scheduling decisions: the ballots / popcounts of the loop head
-                // are a sizeable part of a 50-instruction step
-#pragma unroll 1
+                // are a sizeable part of a 60-instruction step.  `at_inner` is carried across the back edge so that one
+                // compare serves the step's EXEC mask and the loop exit.
+                bool at_inner = (uint32_t)tv.node < n_inner_u;
+#pragma unroll
                 for (int burst = 0; burst < 4; burst++) {
-                    if (tv.node >= 0 && tv.node < P.n_inner) {
-                        trav_step_inner<ITERS, NARROW>(tv, ns, ro, inv, my_stack, ts);
-                        if (tv.node < 0) result_ready = true;
-                    }
-                    if (COUNT && burst > 0) { ts.w_iters++; ts.w_alive += (uint32_t)__popcll(alive_mask); }
-                    if (COUNT) ts.l_inner += burst > 0 ? (uint32_t)__popcll(__ballot(tv.node >= 0 && tv.node < P.n_inner)) : 0u;
-                    if (__ballot(tv.node >= 0 && tv.node < P.n_inner) == 0ull) break;
+                    if (at_inner) trav_step_inner<ITERS, NARROW, ALL_CACHED>(tv, ns, ro, inv, my_stack, ts);
+                    at_inner = (uint32_t)tv.node < n_inner_u;
+                    const unsigned long long m = __ballot(at_inner);
+                    if (COUNT && burst > 0) { ts.w_iters++; ts.w_alive += n_alive; }
+                    if (COUNT && burst < 3) ts.l_inner += (uint32_t)__popcll(m);
+                    if (m == 0ull) break;
                 }
                 if (COUNT) { const unsigned long long now = __builtin_amdgcn_s_memtime(); t_inner += now - t_mark; t_mark = now; }
             }
@@ -672,7 +665,7 @@ __global__ __launch_bounds__(64) void trace_rays_kernel(const RenderParams P, co
     V3 o = mk(0, 0, 0), d = mk(0, 0, 1);
     if (active) { o = mk(rays[6 * k + 0], rays[6 * k + 1], rays[6 * k + 2]); d = mk(rays[6 * k + 3], rays[6 * k + 4], rays[6 * k + 5]); }
     TravStats ts;
-    Trav tv; tv.node = -1; tv.sp = 0; tv.top = -1; tv.c = kFltMax; tv.hit = -1; tv.nf[0] = tv.nf[1] = tv.nf[2] = 0u;
+    Trav tv; tv.node = kTravIdle; tv.sp = 0; tv.top = -1; tv.c = kFltMax; tv.hit = -1; tv.nf[0] = tv.nf[1] = tv.nf[2] = 0u;
     const V3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     if (active) trav_begin<false>(tv, P.tris, P.root_ref, o, d, ts);
     NodeSrc ns;
@@ -680,10 +673,11 @@ __global__ __launch_bounds__(64) void trace_rays_kernel(const RenderParams P, co
     ns.global_fringe = make_rsrc(P.fringe, (uint32_t)(P.n_records - P.n_inner) * 128u);
     ns.n_inner = P.n_inner;
     ns.lds_q0 = ns.lds_q1 = ns.lds_q2 = nullptr; ns.lds_r0 = ns.lds_r1 = nullptr; ns.n_cached = 0;
-    StackRef my_stack; my_stack.s16 = nullptr; my_stack.s32 = (lds_u32 *)s_stack + lane;
+    StackRef my_stack; my_stack.s16 = nullptr; my_stack.s32 = (lds_i32 *)s_stack + lane;
+    stack_init<false>(my_stack);
     while (__ballot(tv.node >= 0) != 0ull) {
         if (tv.node >= P.n_inner) trav_step_fringe<false, false>(tv, ns, o, d, inv, my_stack, ts);
-        else if (tv.node >= 0) trav_step_inner<false, false>(tv, ns, o, inv, my_stack, ts);   // n_cached = 0: global records
+        else if (tv.node >= 0) trav_step_inner<false, false, false>(tv, ns, o, inv, my_stack, ts);   // n_cached = 0: global records
     }
     const float t = tv.c;
     const int tri = tv.hit;
@@ -740,8 +734,8 @@ hipError_t launch_init_rng(uint32_t *rng, uint32_t n_lanes, uint64_t seed, hipSt
     return hipGetLastError();
 }
 
-template <int MODE, bool NARROW>
-static hipError_t launch_render_mode(const RenderParams &p_in, uint32_t n_cu, hipStream_t st) {
+template <int MODE, bool NARROW, bool ALL_CACHED>
+static hipError_t launch_render_cached(const RenderParams &p_in, uint32_t n_cu, hipStream_t st) {
     RenderParams p = p_in;
     int wpb = 1, n_cached = 0;
     render_launch_shape(p.stack_depth, p.n_records, p.n_inner, wpb, n_cached);
@@ -754,7 +748,7 @@ static hipError_t launch_render_mode(const RenderParams &p_in, uint32_t n_cu, hi
     // per launch, not once per process: the attribute belongs to the function ON THE CURRENT DEVICE, and one process may
     // drive several GPUs (srt_comm_init_all); the call is a host-side table update
     {
-        const hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<MODE, NARROW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget);
+        const hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<MODE, NARROW, ALL_CACHED>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget);
         if (ae != hipSuccess) return ae;
     }
     // persistent waves: fill every CU (16 waves per CU at this kernel's register budget), never more waves than tiles
@@ -762,8 +756,15 @@ static hipError_t launch_render_mode(const RenderParams &p_in, uint32_t n_cu, hi
     uint32_t n_waves = n_cu * waves_per_cu;
     if (n_waves > p.queue_rows_bound) n_waves = p.queue_rows_bound;     // never more waves than queue rows (upper bound known to the host)
     const uint32_t n_blocks = (n_waves + (uint32_t)wpb - 1) / (uint32_t)wpb;
-    hipLaunchKernelGGL((render_kernel<MODE, NARROW>), dim3(n_blocks), dim3(64 * wpb), lds, st, p);
+    hipLaunchKernelGGL((render_kernel<MODE, NARROW, ALL_CACHED>), dim3(n_blocks), dim3(64 * wpb), lds, st, p);
     return hipGetLastError();
+}
+
+template <int MODE, bool NARROW>
+static hipError_t launch_render_mode(const RenderParams &p, uint32_t n_cu, hipStream_t st) {
+    int wpb = 1, n_cached = 0;
+    render_launch_shape(p.stack_depth, p.n_records, p.n_inner, wpb, n_cached);
+    return n_cached == p.n_inner ? launch_render_cached<MODE, NARROW, true>(p, n_cu, st) : launch_render_cached<MODE, NARROW, false>(p, n_cu, st);
 }
 
 hipError_t launch_render(const RenderParams &p, uint32_t n_cu, int mode, hipStream_t st) {
@@ -799,7 +800,7 @@ hipError_t launch_unswizzle(const float *const src[3], float *const dst[3], uint
 
 hipError_t launch_trace(const RenderParams &p, const float *rays, size_t n, float *out, hipStream_t st) {
     if (n == 0) return hipSuccess;
-    const size_t lds = (size_t)(p.stack_depth < 1 ? 1 : p.stack_depth) * 64 * 4;
+    const size_t lds = stack_slots(p.stack_depth) * 64 * 4;
     hipLaunchKernelGGL(trace_rays_kernel, dim3((uint32_t)((n + 63) / 64)), dim3(64), lds, st, p, rays, (uint32_t)n, out);
     return hipGetLastError();
 }

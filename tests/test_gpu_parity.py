@@ -227,16 +227,17 @@ def test_ragged_chunks_multi_rank_match_oracle(srt, orc):
 def test_queue_scheduling_does_not_change_results(srt, gpu, orc, monkeypatch):
     """The pixel queue (cost order, expensive tiles split over several waves with parked lanes) is pure scheduling: the
     framebuffer is bit-identical with splitting off, with the default policy and with the most aggressive policy, and for
-    different step-choice rules (score weights, the older thresholds)."""
+    different step-choice weights."""
     scene = srt.Scene.builtin(srt.SCENE_RANDOM_SPHERES).build_bvh(srt.BVH_SAH, 1984)
     W, H, spp, depth = 120, 72, 12, 16          # spp > 8: the cost probe and the ordered queue are active
     cam = scene.default_camera(W, H)
     ref = None
     for env in ({"SRT_SPLIT_LOAD": "0"}, {}, {"SRT_SPLIT_LOAD": "1"},
-                {"SRT_SPLIT_LOAD": "1", "SRT_SCORE_SHADE": "0", "SRT_SHADE_THRESHOLD": "3", "SRT_FRINGE_THRESHOLD": "60"},
-                {"SRT_SCORE_SHADE": "0"}, {"SRT_SCORE_SHADE": "2000", "SRT_SCORE_FRINGE": "1"}, {"SRT_SCORE_SHADE": "1", "SRT_SCORE_FRINGE": "4000"},
+                {"SRT_SPLIT_LOAD": "1", "SRT_SCORE_SHADE": "9", "SRT_SCORE_FRINGE": "900"},
+                {"SRT_SCORE_SHADE": "2000", "SRT_SCORE_FRINGE": "1"}, {"SRT_SCORE_SHADE": "1", "SRT_SCORE_FRINGE": "4000"},
+                {"SRT_SCORE_FRINGE": "0"},      # clamped to 1: a zero weight would starve lanes at fringe records
                 {"SRT_PROBE_SPP": "0"}):
-        for k in ("SRT_SPLIT_LOAD", "SRT_SHADE_THRESHOLD", "SRT_FRINGE_THRESHOLD", "SRT_PROBE_SPP", "SRT_SCORE_SHADE", "SRT_SCORE_FRINGE"):
+        for k in ("SRT_SPLIT_LOAD", "SRT_PROBE_SPP", "SRT_SCORE_SHADE", "SRT_SCORE_FRINGE"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
