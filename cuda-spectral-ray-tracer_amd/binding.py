@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsrt_hip.so")
+LIB_PATH = os.environ.get("SRT_LIB_PATH") or os.path.join(_HERE, "libsrt_hip.so")   # (override: kernel experiments only)
 
 N_CIE = 95
 TILE_PLANES = 9
@@ -99,6 +99,22 @@ PROTOTYPES = {
     "srt_trace_rays": (_i, [_vp, _fp, _sz, _fp]),
     "srt_device_op_sweep": (_i, [_vp, _i, _fp, _fp, _sz, _fp]),
     "srt_calibrate": (_i, [_vp, _i, _u32, _u32, C.POINTER(Calibration)]),
+    "srt_ctx_device": (_i, [_vp]),
+    "srt_comm_init_all": (_i, [C.POINTER(_i), _i, C.POINTER(_vp)]),
+    "srt_comm_unique_id": (_i, [C.POINTER(C.c_ubyte)]),
+    "srt_comm_init_rank": (_i, [_vp, C.POINTER(C.c_ubyte), _u32, _u32, C.POINTER(_vp)]),
+    "srt_comm_destroy": (None, [_vp]),
+    "srt_comm_last_error": (C.c_char_p, [_vp]),
+    "srt_comm_world": (_u32, [_vp]),
+    "srt_comm_local_count": (_u32, [_vp]),
+    "srt_comm_ctx": (_vp, [_vp, _u32]),
+    "srt_comm_root_ctx": (_vp, [_vp]),
+    "srt_comm_upload_scene": (_i, [_vp, _vp]),
+    "srt_comm_set_camera": (_i, [_vp, C.POINTER(CameraData)]),
+    "srt_comm_init_device_params": (_i, [_vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _u64]),
+    "srt_render_frame_multi": (_i, [_vp, _u32, _u32, _u32, _u32]),
+    "srt_comm_synchronize": (_i, [_vp]),
+    "srt_comm_stats": (_i, [_vp, C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_f)]),
 }
 
 
@@ -125,6 +141,16 @@ def lib():
             fn.argtypes = args
         _lib = L
     return _lib
+
+
+COMM_ID_BYTES = 128
+
+
+def check_comm(code, comm=None):
+    if code is not None and code < 0:
+        msg = lib().srt_comm_last_error(comm)
+        raise SrtError(code, msg.decode() if msg else "")
+    return code
 
 
 def check(code, ctx=None):

@@ -154,6 +154,8 @@ void srt_destroy(srt_ctx *c) {
     delete c;
 }
 
+int srt_ctx_device(const srt_ctx *ctx) { return ctx ? ctx->device : -1; }
+
 const char *srt_last_error(const srt_ctx *ctx) { return ctx ? ctx->err.c_str() : global_error(); }
 
 int srt_upload_scene(srt_ctx *c, const srt_scene *s) {

@@ -297,7 +297,7 @@ typedef __attribute__((address_space(3))) const f2 lds_cf2;
 typedef __attribute__((address_space(3))) const char lds_cchar;
 struct NodeSrc {
     buf_rsrc global_nodes;               // INNER records, 64 B each
-    buf_rsrc global_fringe;              // FRINGE records, 128 B each, indexed by record - n_inner
+    buf_rsrc global_fringe;              // FRINGE records, 96 B each, indexed by record - n_inner
     int n_inner;
     lds_cf4 *lds_q0, *lds_q1, *lds_q2;   // x / y / z planes
     lds_cu32 *lds_r0, *lds_r1;           // NARROW: r0 = lref | rref << 16; else r0 = lref, r1 = rref
@@ -430,44 +430,51 @@ __device__ __forceinline__ void trav_step_inner(Trav &tv, const NodeSrc &ns, V3 
 template <bool COUNT, bool NARROW>
 __device__ __forceinline__ void trav_step_fringe(Trav &tv, const NodeSrc &ns, V3 o, V3 d,
                                                  V3 inv, const StackRef &stack, TravStats &ts) {
-    // one round of independent loads: header + a 48-byte block per child (box or triangle, see flatten_scene)
-    const uint32_t off = (uint32_t)(tv.node - ns.n_inner) * 128u;
-    const f4v hd = buf_load16(ns.global_fringe, off);
-    const f4v al = buf_load16(ns.global_fringe, off + 16u), bl = buf_load16(ns.global_fringe, off + 32u), cl = buf_load16(ns.global_fringe, off + 48u);
-    const f4v ar = buf_load16(ns.global_fringe, off + 64u), br = buf_load16(ns.global_fringe, off + 80u), cr = buf_load16(ns.global_fringe, off + 96u);
+    // one round of independent loads: 12 (left, right) pairs = six 16-byte loads (record layout: flatten_scene)
+    const uint32_t off = __umul24((uint32_t)(tv.node - ns.n_inner), 96u);   // (full-rate 24-bit multiply; < 2^24 fringe records)
+    const f4v q0 = buf_load16(ns.global_fringe, off), q1 = buf_load16(ns.global_fringe, off + 16u), q2 = buf_load16(ns.global_fringe, off + 32u);
+    const f4v q3 = buf_load16(ns.global_fringe, off + 48u), q4 = buf_load16(ns.global_fringe, off + 64u), q5 = buf_load16(ns.global_fringe, off + 80u);
     const int below = stack_exchange<NARROW>(stack, tv.sp, tv.top);
-    const int lref = (int)__float_as_uint(hd.x), rref = (int)__float_as_uint(hd.y);
+    const f2 w0 = mk2(q0.x, q0.y), w1 = mk2(q0.z, q0.w), w2 = mk2(q1.x, q1.y), w3 = mk2(q1.z, q1.w), w4 = mk2(q2.x, q2.y), w5 = mk2(q2.z, q2.w);
+    const f2 w6 = mk2(q3.x, q3.y), w7 = mk2(q3.z, q3.w), w8 = mk2(q4.x, q4.y), w9 = mk2(q4.z, q4.w);
+    const uint32_t fl = __float_as_uint(q5.x), fr = __float_as_uint(q5.y);
+    const int lref = (int)__float_as_uint(q5.z), rref = (int)__float_as_uint(q5.w);
     const bool leaf_l = lref < 0, leaf_r = rref < 0;
     if (COUNT) { ts.n_iters++; ts.n_tri += (leaf_l ? 1u : 0u) + (leaf_r ? 1u : 0u); ts.n_box += (leaf_l ? 0u : 1u) + (leaf_r ? 0u : 1u); }
 
-    // ---- both child boxes; a leaf child's block holds a triangle, its box result is ignored --------------------------
+    // ---- both child boxes (words 0-5 = xmin xmax ymin ymax zmin zmax); a leaf child's words hold a triangle, its box result
+    // is ignored ------------------------------------------------------------------------------------------------------
     float e_l, m_l, e_r, m_r;
     {
         const bool px = inv.x >= 0, py = inv.y >= 0, pz = inv.z >= 0;
         BoxPairs b;
-        b.nx = mk2(px ? al.x : al.y, px ? ar.x : ar.y); b.fx = mk2(px ? al.y : al.x, px ? ar.y : ar.x);
-        b.ny = mk2(py ? al.z : al.w, py ? ar.z : ar.w); b.fy = mk2(py ? al.w : al.z, py ? ar.w : ar.z);
-        b.nz = mk2(pz ? bl.x : bl.y, pz ? br.x : br.y); b.fz = mk2(pz ? bl.y : bl.x, pz ? br.y : br.x);
+        b.nx = px ? w0 : w1; b.fx = px ? w1 : w0;
+        b.ny = py ? w2 : w3; b.fy = py ? w3 : w2;
+        b.nz = pz ? w4 : w5; b.fz = pz ? w5 : w4;
         box_pair(b, o, inv, e_l, m_l, e_r, m_r);
     }
 
-    // ---- both leaf triangles in one segment (a fringe record has at least one; the other side's values are ignored) -----
-    const f2 nx = mk2(al.x, ar.x), ny = mk2(al.y, ar.y), nz = mk2(al.z, ar.z), D = mk2(al.w, ar.w);
-    const f2 denom = nx * d.x + ny * d.y + nz * d.z;                      // dot(normal, dir), tri.cu:9
-    const f2 num = D - (nx * o.x + ny * o.y + nz * o.z);                  // D - dot(normal, origin), tri.cu:17
+    // ---- both leaf triangles in one segment (words 0-9 = n.x n.y n.z D v0w v0h v1w v1h v2w v2h; a fringe record has at
+    // least one leaf, the other side's values are ignored) ----------------------------------------------------------------
+    const f2 denom = w0 * d.x + w1 * d.y + w2 * d.z;                      // dot(normal, dir), tri.cu:9
+    const f2 num = w3 - (w0 * o.x + w1 * o.y + w2 * o.z);                 // D - dot(normal, origin), tri.cu:17
     const f2 t = mk2(num.x / denom.x, num.y / denom.y);
-    const uint32_t fl = __float_as_uint(cl.z), fr = __float_as_uint(cr.z);
     const bool wyl = fl & kTriWIsY, hzl = fl & kTriHIsZ, wyr = fr & kTriWIsY, hzr = fr & kTriHIsZ;
     // intersection = orig + t*dir (ray.cuh:31-34), the two projected components
     const f2 pw = mk2(wyl ? o.y : o.x, wyr ? o.y : o.x) + t * mk2(wyl ? d.y : d.x, wyr ? d.y : d.x);
     const f2 ph = mk2(hzl ? o.z : o.y, hzr ? o.z : o.y) + t * mk2(hzl ? d.z : d.y, hzr ? d.z : d.y);
     // double_signed_area_2D(v1,v2,v3) = (v1[w]-v3[w])*(v2[h]-v3[h]) - (v2[w]-v3[w])*(v1[h]-v3[h])   (tri.cu:181)
-    const f2 v0w = mk2(bl.x, br.x), v0h = mk2(bl.y, br.y), v1w = mk2(bl.z, br.z), v1h = mk2(bl.w, br.w), v2w = mk2(cl.x, cr.x), v2h = mk2(cl.y, cr.y);
-    const f2 a1 = (pw - v1w) * (v0h - v1h) - (v0w - v1w) * (ph - v1h);     // (p, v0, v1)
-    const f2 a2 = (pw - v2w) * (v1h - v2h) - (v1w - v2w) * (ph - v2h);     // (p, v1, v2)
-    const f2 a3 = (pw - v0w) * (v2h - v0h) - (v2w - v0w) * (ph - v0h);     // (p, v2, v0)
-    const bool in_l = (fl & kTriClockwise) ? (a1.x >= 0.f) & (a2.x >= 0.f) & (a3.x >= 0.f) : (a1.x <= 0.f) & (a2.x <= 0.f) & (a3.x <= 0.f);
-    const bool in_r = (fr & kTriClockwise) ? (a1.y >= 0.f) & (a2.y >= 0.f) & (a3.y >= 0.f) : (a1.y <= 0.f) & (a2.y <= 0.f) & (a3.y <= 0.f);
+    const f2 a1 = (pw - w6) * (w5 - w7) - (w4 - w6) * (ph - w7);     // (p, v0, v1)
+    const f2 a2 = (pw - w8) * (w7 - w9) - (w6 - w8) * (ph - w9);     // (p, v1, v2)
+    const f2 a3 = (pw - w4) * (w9 - w5) - (w8 - w4) * (ph - w5);     // (p, v2, v0)
+    // is_interior_faster (tri.cu:121-128): all three areas >= 0 for a clockwise triangle, all <= 0 otherwise.  `a <= 0` is
+    // `-a >= 0` for every float (zeros of either sign pass both, NaN fails both), and -a is a flip of the sign bit, which the
+    // record holds in bit 31 of the flags word for counter-clockwise triangles: one code path, no branch.
+    const uint32_t sl = fl & 0x80000000u, sr = fr & 0x80000000u;
+    const bool in_l = (__uint_as_float(__float_as_uint(a1.x) ^ sl) >= 0.f) & (__uint_as_float(__float_as_uint(a2.x) ^ sl) >= 0.f) &
+                      (__uint_as_float(__float_as_uint(a3.x) ^ sl) >= 0.f);
+    const bool in_r = (__uint_as_float(__float_as_uint(a1.y) ^ sr) >= 0.f) & (__uint_as_float(__float_as_uint(a2.y) ^ sr) >= 0.f) &
+                      (__uint_as_float(__float_as_uint(a3.y) ^ sr) >= 0.f);
     // plane not parallel, t >= tmin, inside (everything but `t <= c`)
     const bool ok_l = leaf_l & !(fabsf(denom.x) < 1e-8f) & (0.0f <= t.x) & in_l;
     const bool ok_r = leaf_r & !(fabsf(denom.y) < 1e-8f) & (0.0f <= t.y) & in_r;

@@ -322,7 +322,7 @@ int flatten_scene(const srt_scene &s, FlatScene &out) {
     const size_t n_tris = s.raw.size(), n_mats = s.mats.size();
     for (size_t k = 0; k < n_tris; k++)
         if (s.raw[k].mat_index >= n_mats) { set_global_error("upload: triangle references a missing material"); return SRT_ERR_INVALID; }
-    if (n_mats >= (1u << 24)) { set_global_error("upload: too many materials"); return SRT_ERR_INVALID; }
+    if (n_mats >= (1u << 23)) { set_global_error("upload: too many materials"); return SRT_ERR_INVALID; }
 
     // triangles: a = {n, D}, b = {v0[w], v0[h], v1[w], v1[h]}, c = {v2[w], v2[h], flags, 0}
     out.tris.assign(12 * n_tris, 0.f);
@@ -370,12 +370,15 @@ int flatten_scene(const srt_scene &s, FlatScene &out) {
     }
     auto child_ref = [&](int32_t k) -> int32_t { return s.nodes[k].prim >= 0 ? ~s.nodes[k].prim : rec_index[k]; };
     // INNER records, 64 B: three axis planes (lo_L, lo_R, hi_L, hi_R), then lref, rref (see NodeSrc in srt_device.h).
-    // FRINGE records, 128 B: lref, rref, two pad words, then one 48-byte block per child -- the child's box
-    // (xmin xmax ymin ymax | zmin zmax 0 0 | 0 0 0 0) when it is internal, a copy of its triangle record when it is a leaf --
-    // so that a fringe visit is ONE round of independent loads instead of record -> triangle.
+    // FRINGE records, 96 B = 12 (left, right) pairs: pair k holds word k of the left child's block and word k of the right
+    // child's block side by side -- a 16-byte load delivers two register pairs that feed the packed arithmetic directly.
+    // A child's 12-word block is its box (xmin xmax ymin ymax zmin zmax 0 ...) when it is internal, a copy of its triangle
+    // record (n.x n.y n.z D | v0w v0h v1w v1h | v2w v2h flags 0) when it is a leaf, so that a fringe visit is ONE round of
+    // independent loads instead of record -> triangle.  Word 10 = flags (bit 31 added here: set for a counter-clockwise
+    // triangle = the sign flip that turns its `area <= 0` tests into `>= 0`), word 11 = the child reference.
     const size_t n_in = (size_t)out.n_inner, n_fr = pre.size() - n_in;
     out.nodes.assign(16 * std::max<size_t>(n_in, 1), 0.f);
-    out.fringe.assign(32 * std::max<size_t>(n_fr, 1), 0.f);
+    out.fringe.assign(24 * std::max<size_t>(n_fr, 1), 0.f);
     for (size_t r = 0; r < pre.size(); r++) {
         const BvhNode &nd = s.nodes[pre[r]];
         const BvhNode &l = s.nodes[nd.left], &rr = s.nodes[nd.right];
@@ -388,14 +391,19 @@ int flatten_scene(const srt_scene &s, FlatScene &out) {
             o[12] = bits_to_float((uint32_t)child_ref(nd.left));
             o[13] = bits_to_float((uint32_t)child_ref(nd.right));
         } else {
-            float *o = &out.fringe[32 * (r - n_in)];
-            o[0] = bits_to_float((uint32_t)child_ref(nd.left));
-            o[1] = bits_to_float((uint32_t)child_ref(nd.right));
+            float *o = &out.fringe[24 * (r - n_in)];
             const BvhNode *ch[2] = {&l, &rr};
+            const int32_t refs[2] = {child_ref(nd.left), child_ref(nd.right)};
             for (int k = 0; k < 2; k++) {
-                float *b = o + 4 + 12 * k;
-                if (ch[k]->prim >= 0) memcpy(b, &out.tris[12 * (size_t)ch[k]->prim], 12 * sizeof(float));
-                else memcpy(b, ch[k]->box, 6 * sizeof(float));
+                float b[12] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                if (ch[k]->prim >= 0) {
+                    memcpy(b, &out.tris[12 * (size_t)ch[k]->prim], 11 * sizeof(float));
+                    uint32_t flags; memcpy(&flags, &b[10], 4);
+                    if (!(flags & 4u)) flags |= 0x80000000u;
+                    b[10] = bits_to_float(flags);
+                } else memcpy(b, ch[k]->box, 6 * sizeof(float));
+                b[11] = bits_to_float((uint32_t)refs[k]);
+                for (int w = 0; w < 12; w++) o[2 * w + k] = b[w];
             }
         }
     }

@@ -74,7 +74,7 @@ bool scene_builtin_known(int scene_id);
 // GPU images of the scene (layout: srt_device.h)
 struct FlatScene {
     std::vector<float> nodes;    // 16 floats per INNER record (both children internal)
-    std::vector<float> fringe;   // 32 floats per FRINGE record (a leaf child; triangle data inline), record index - n_inner
+    std::vector<float> fringe;   // 24 floats per FRINGE record (a leaf child; triangle data inline, (left, right) pairs), record index - n_inner
     std::vector<float> tris;     // 12 floats per triangle
     std::vector<float> mat_sd;   // 192 floats per material
     std::vector<float> mat_par;  // 8 floats per material

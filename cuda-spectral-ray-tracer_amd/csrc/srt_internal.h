@@ -14,7 +14,7 @@ constexpr int kCounters = 16;       // rays, node_visits, tri_tests, box_tests, 
 struct RenderParams {
     // scene (HBM layout: DESIGN.md)
     const float4 *nodes;       // 4 float4 per INNER record (records [0, n_inner))
-    const float4 *fringe;      // 8 float4 per FRINGE record (records [n_inner, n_records)), triangle data inline
+    const float4 *fringe;      // 6 float4 per FRINGE record (records [n_inner, n_records)), triangle data inline
     const float4 *tris;        // 3 float4 per triangle
     const float2 *mat_sd;      // per material 96 pairs (94 used): (sd[k], sd[k+1])
     const float4 *mat_par;     // per material 2 float4: {bits(type), fuzz, B0, B1}, {B2, C0, C1, C2}

@@ -43,6 +43,10 @@ template <typename T>
 __device__ __forceinline__ T *join_ptr(uint32_t lo, uint32_t hi) { return reinterpret_cast<T *>(((unsigned long long)hi << 32) | lo); }
 
 constexpr size_t kLdsBudget = 160 * 1024;
+#ifndef SRT_INNER_BURST
+#define SRT_INNER_BURST 4
+#endif
+constexpr int kInnerBurst = SRT_INNER_BURST;   // inner steps between two scheduling decisions (fully unrolled)
 static inline size_t round16(size_t v) { return (v + 15) & ~(size_t)15; }
 static inline bool narrow_refs(int n_records) { return n_records <= 32767; }   // 15 bits: a 16-bit stack slot also holds the sentinel -1
 static inline size_t cache_bytes(int n_cached, int n_records) { return round16((size_t)n_cached * (narrow_refs(n_records) ? 52 : 56)); }
@@ -150,7 +154,7 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
 
     NodeSrc ns;
     ns.global_nodes = make_rsrc(P.nodes, (uint32_t)P.n_inner * 64u);
-    ns.global_fringe = make_rsrc(P.fringe, (uint32_t)(P.n_records - P.n_inner) * 128u);
+    ns.global_fringe = make_rsrc(P.fringe, (uint32_t)(P.n_records - P.n_inner) * 96u);
     ns.n_inner = P.n_inner;
     ns.lds_q0 = (lds_cf4 *)s_q0; ns.lds_q1 = (lds_cf4 *)s_q1; ns.lds_q2 = (lds_cf4 *)s_q2;
     ns.lds_r0 = (lds_cu32 *)s_r0; ns.lds_r1 = (lds_cu32 *)s_r1;
@@ -481,12 +485,12 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
                 // compare serves the step's EXEC mask and the loop exit.
                 bool at_inner = (uint32_t)tv.node < n_inner_u;
 #pragma unroll
-                for (int burst = 0; burst < 4; burst++) {
+                for (int burst = 0; burst < kInnerBurst; burst++) {
                     if (at_inner) trav_step_inner<ITERS, NARROW, ALL_CACHED>(tv, ns, ro, inv, my_stack, ts);
                     at_inner = (uint32_t)tv.node < n_inner_u;
                     const unsigned long long m = __ballot(at_inner);
                     if (COUNT && burst > 0) { ts.w_iters++; ts.w_alive += n_alive; }
-                    if (COUNT && burst < 3) ts.l_inner += (uint32_t)__popcll(m);
+                    if (COUNT && burst < kInnerBurst - 1) ts.l_inner += (uint32_t)__popcll(m);
                     if (m == 0ull) break;
                 }
                 if (COUNT) { const unsigned long long now = __builtin_amdgcn_s_memtime(); t_inner += now - t_mark; t_mark = now; }
@@ -670,7 +674,7 @@ __global__ __launch_bounds__(64) void trace_rays_kernel(const RenderParams P, co
     if (active) trav_begin<false>(tv, P.tris, P.root_ref, o, d, ts);
     NodeSrc ns;
     ns.global_nodes = make_rsrc(P.nodes, (uint32_t)P.n_inner * 64u);
-    ns.global_fringe = make_rsrc(P.fringe, (uint32_t)(P.n_records - P.n_inner) * 128u);
+    ns.global_fringe = make_rsrc(P.fringe, (uint32_t)(P.n_records - P.n_inner) * 96u);
     ns.n_inner = P.n_inner;
     ns.lds_q0 = ns.lds_q1 = ns.lds_q2 = nullptr; ns.lds_r0 = ns.lds_r1 = nullptr; ns.n_cached = 0;
     StackRef my_stack; my_stack.s16 = nullptr; my_stack.s32 = (lds_i32 *)s_stack + lane;

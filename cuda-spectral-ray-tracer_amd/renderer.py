@@ -16,16 +16,21 @@ def reference_grid(chunk_w, chunk_h, tx=DEFAULT_TX, ty=DEFAULT_TY):
 
 
 class Renderer:
-    def __init__(self, device=0):
-        h = C.c_void_p()
-        B.check(B.lib().srt_create(int(device), C.byref(h)))
-        self._h = h
-        self.device = device
+    def __init__(self, device=0, _borrowed=None):
+        if _borrowed is not None:            # a context owned by a communicator (srt_comm_init_all)
+            self._h, self._owned = C.c_void_p(_borrowed), False
+            self.device = B.lib().srt_ctx_device(self._h)
+        else:
+            h = C.c_void_p()
+            B.check(B.lib().srt_create(int(device), C.byref(h)))
+            self._h, self._owned = h, True
+            self.device = device
         self.geom = None
 
     def close(self):
         if getattr(self, "_h", None):
-            B.lib().srt_destroy(self._h)
+            if self._owned:
+                B.lib().srt_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -138,6 +143,87 @@ class Renderer:
         out = np.zeros_like(a)
         self._ck(B.lib().srt_device_op_sweep(self._h, which, B.fptr(a), B.fptr(b), a.size, B.fptr(out)))
         return out
+
+
+class Comm:
+    """Multi-GPU communicator (srt_comm): W ranks render interleaved 8x8 tiles of a chunk, one RCCL gather to rank 0.
+    Comm.init_all(devices): one process drives several GPUs.  Comm.init_rank(renderer, id, rank, world): one process per
+    GPU, `id` from Comm.unique_id() on rank 0."""
+
+    def __init__(self, handle, renderers, owns):
+        self._h, self.renderers, self._owns = handle, renderers, owns
+        self.world = B.lib().srt_comm_world(handle)
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_ubyte * B.COMM_ID_BYTES)()
+        B.check_comm(B.lib().srt_comm_unique_id(buf))
+        return bytes(buf)
+
+    @classmethod
+    def init_all(cls, devices):
+        arr = (C.c_int * len(devices))(*devices)
+        h = C.c_void_p()
+        B.check_comm(B.lib().srt_comm_init_all(arr, len(devices), C.byref(h)))
+        rs = [Renderer(_borrowed=B.lib().srt_comm_ctx(h, k)) for k in range(B.lib().srt_comm_local_count(h))]
+        return cls(h, rs, True)
+
+    @classmethod
+    def init_rank(cls, renderer, comm_id, rank, world):
+        buf = (C.c_ubyte * B.COMM_ID_BYTES).from_buffer_copy(comm_id)
+        h = C.c_void_p()
+        B.check_comm(B.lib().srt_comm_init_rank(renderer._h, buf, rank, world, C.byref(h)))
+        return cls(h, [renderer], False)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            B.lib().srt_comm_destroy(self._h)
+            self._h = None
+            for r in self.renderers:
+                if not r._owned:
+                    r._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, code):
+        return B.check_comm(code, self._h)
+
+    @property
+    def root(self):
+        """rank 0's renderer (holds the assembled framebuffer), None when rank 0 lives in another process"""
+        p = B.lib().srt_comm_root_ctx(self._h)
+        for r in self.renderers:
+            if r._h and r._h.value == p:
+                return r
+        return None
+
+    def upload_scene(self, scene):
+        self._ck(B.lib().srt_comm_upload_scene(self._h, scene.handle))
+
+    def set_camera(self, cam):
+        self._ck(B.lib().srt_comm_set_camera(self._h, C.byref(cam)))
+
+    def init_device_params(self, chunk_w, chunk_h, spp, bounce_limit, seed=1984, tx=DEFAULT_TX, ty=DEFAULT_TY, bx=None, by=None):
+        if bx is None or by is None:
+            bx, by = reference_grid(chunk_w, chunk_h, tx, ty)
+        self._ck(B.lib().srt_comm_init_device_params(self._h, tx, ty, bx, by, chunk_w, chunk_h, spp, bounce_limit, seed))
+        for r in self.renderers:
+            r.geom = dict(tx=tx, ty=ty, bx=bx, by=by, chunk_w=chunk_w, chunk_h=chunk_h, n_lanes=tx * ty * bx * by)
+
+    def render_frame(self, width, height, offx=0, offy=0):
+        self._ck(B.lib().srt_render_frame_multi(self._h, width, height, offx, offy))
+
+    def synchronize(self):
+        self._ck(B.lib().srt_comm_synchronize(self._h))
+
+    def stats(self):
+        rays, paths, ms = C.c_uint64(), C.c_uint64(), C.c_float()
+        self._ck(B.lib().srt_comm_stats(self._h, C.byref(rays), C.byref(paths), C.byref(ms)))
+        return dict(rays=rays.value, paths=paths.value, max_kernel_ms=ms.value)
 
 
 def render_image(scene, cam, width, height, spp, bounce_limit, seed=1984, device=0, count_traversal=False, renderer=None):

@@ -209,6 +209,43 @@ SRT_API int srt_trace_rays(srt_ctx *ctx, const float *rays, size_t n, float *out
  * sweep"); used to prove the device's + - * / sqrt fmin cast and srt_powf bits equal the host's. */
 SRT_API int srt_device_op_sweep(srt_ctx *ctx, int which, const float *a, const float *b, size_t n, float *out);
 
+SRT_API int srt_ctx_device(const srt_ctx *ctx);               /* HIP device index of the context */
+
+/* ---------------------------------------------------------------------------------------------------
+ * Multi-GPU.  The reference's caller renders chunk after chunk on ONE GPU
+ * (render_manager::step, rendering/render_manager.cu:3-66); a communicator fans one chunk out over W GPUs:
+ * rank r renders the 8x8-pixel tiles t with t % W == r, ONE RCCL gather (xGMI inside a node) brings the
+ * compact tile buffers to rank 0, which scatters them into its block-linear framebuffer.  The image is
+ * bit-identical for every W (per-pixel seeds, rendering.cu:137).  RCCL is loaded (dlopen) on first use.
+ * ------------------------------------------------------------------------------------------------- */
+#define SRT_COMM_ID_BYTES 128
+typedef struct srt_comm srt_comm;
+/* One process drives n GPUs: creates one context per device (rank i = devices[i]) and an RCCL communicator
+ * over them (ncclCommInitAll), one HIP stream per device. */
+SRT_API int srt_comm_init_all(const int *devices, int n, srt_comm **out);
+/* One process per GPU (torch.distributed.run, mpirun): rank 0 calls srt_comm_unique_id and hands the 128 bytes
+ * to the other ranks by any channel; every rank then wraps its own context.  Sets the context's partition. */
+SRT_API int srt_comm_unique_id(unsigned char id[SRT_COMM_ID_BYTES]);
+SRT_API int srt_comm_init_rank(srt_ctx *ctx, const unsigned char id[SRT_COMM_ID_BYTES], uint32_t rank, uint32_t world, srt_comm **out);
+SRT_API void srt_comm_destroy(srt_comm *comm);                 /* destroys the contexts srt_comm_init_all created */
+SRT_API const char *srt_comm_last_error(const srt_comm *comm);
+SRT_API uint32_t srt_comm_world(const srt_comm *comm);
+SRT_API uint32_t srt_comm_local_count(const srt_comm *comm);   /* contexts this process drives */
+SRT_API srt_ctx *srt_comm_ctx(srt_comm *comm, uint32_t local_index);
+SRT_API srt_ctx *srt_comm_root_ctx(srt_comm *comm);            /* rank 0's context (holds the assembled framebuffer) or NULL */
+/* srt_upload_scene / srt_set_camera / srt_init_device_params on every local context (the scene is replicated). */
+SRT_API int srt_comm_upload_scene(srt_comm *comm, const srt_scene *s);
+SRT_API int srt_comm_set_camera(srt_comm *comm, const srt_camera_data *cam);
+SRT_API int srt_comm_init_device_params(srt_comm *comm, uint32_t tx, uint32_t ty, uint32_t bx, uint32_t by, uint32_t chunk_w,
+                                        uint32_t chunk_h, uint32_t spp, uint32_t bounce_limit, uint64_t seed);
+/* renderer::render(w,h,offx,offy) on W GPUs: render kernels on every local rank's stream, one ncclGather of the tile
+ * buffers to rank 0, one scatter kernel there.  Asynchronous; srt_comm_synchronize waits for the local streams.
+ * Afterwards rank 0's context answers srt_read_fb / srt_read_fb_rowmajor / srt_dev_fb as after srt_render_chunk. */
+SRT_API int srt_render_frame_multi(srt_comm *comm, uint32_t width, uint32_t height, uint32_t offx, uint32_t offy);
+SRT_API int srt_comm_synchronize(srt_comm *comm);
+/* Closest-hit queries / paths of the last frame summed over the local ranks, and the slowest local render kernel. */
+SRT_API int srt_comm_stats(srt_comm *comm, uint64_t *rays, uint64_t *paths, float *max_kernel_ms);
+
 /* Issue-rate calibration (no reference counterpart: measurement support for bench.py's roofline).  Runs microkernel
  * `kind` (csrc/srt_calib.hip: 0 v_add_f32, 1 v_pk_mul_f32, 2 v_fma_f32, 3 dependent v_add_f32 chain, 4 s_add_u32,
  * 5 v_add_f32 + s_add_u32 interleaved, 6 v_cmp + v_cndmask, 7 / 8 ds_read_b64 linear / random, 9 v_max3_f32,
