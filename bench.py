@@ -3,22 +3,31 @@
 
 Metric (BASELINE.json): Mray/s on the synthetic "random spheres" scene, 1920x1080, 1024 spp, depth 16
 (config[2]; a ray = one closest-hit query).  One *step* = one full render of that image: every rank
-renders its interleaved 8x8 tiles with the HIP kernel, ONE gather (RCCL over xGMI) brings the compact
-tile buffers to rank 0, which scatters them into the block-linear planar framebuffer in HBM.  Scene,
-camera and RNG states are resident in HBM before the timed region.  The image is fixed, so N GPUs split
-the same work: scaling is "strong".
+renders its interleaved 8x8 tiles with the HIP kernel, ONE gather (RCCL over xGMI, issued by the library:
+srt_render_frame_multi) brings the compact tile buffers to rank 0, which scatters them into the
+block-linear planar framebuffer in HBM.  Scene, camera and RNG states are resident in HBM before the timed
+region.  The image is fixed, so N GPUs split the same work: scaling is "strong".
 
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints ONE JSON line.  `roofline` prices the render kernel against HBM with the ALGORITHMIC bytes
-per ray of SURVEY 8(d) (B_ray = V*64 + T*48 + 56; V, T measured by the instrumented kernel on the same
-scene); `cpu_baseline` is the CPU oracle (a port: the reference has no CPU path) timed on this box's host
-cores on a bounded sample of the same workload.
+Rank 0 prints ONE JSON line.
+
+`roofline` prices the render kernel against what actually binds it.  The scene is LDS / L2 resident, so HBM is
+not the roof (the SURVEY 8(d) HBM figure is kept under roofline.hbm, against the copy bandwidth measured in this
+run).  The kernel is a divergent VALU program; the roof is the rate at which the chip issues wave64 vector
+instructions with the 4 resident waves per SIMD this kernel runs.  That rate is MEASURED in this run by the
+library's calibration microkernel (srt_calibrate, csrc/srt_calib.hip: independent v_add_f32, 4 waves / SIMD, every
+CU), times 64 lanes = peak lane-ops/s.  achieved = useful VALU lane-ops per ray (active lanes summed over every
+vector instruction: SQ_THREAD_CYCLES_VALU / rays from the committed rocprofv3 --pmc pass of THIS kernel version,
+profiles/r02/lane_ops_per_ray.json -- imported, and labelled so) x rays per launch (live) / render-kernel time
+(live, HIP events on the launch stream).
+
+`cpu_baseline` is the CPU oracle (a port: the reference has no CPU path) timed on this box's host cores on a
+bounded sample of the same workload, plus BASELINE.md's "config 1, one thread, full size" leg.
 """
 import argparse
-import importlib
 import json
 import os
 import sys
@@ -27,25 +36,33 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy rate
+HBM_SPEC_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); the copy rate is measured below
 NODE_BYTES, TRI_BYTES, MAT_BYTES = 64, 48, 56
+LANE_OPS_FILE = os.path.join(ROOT, "profiles", "r02", "lane_ops_per_ray.json")
+SCENE_NAMES = {0: "reference CORNELL scene", 1: "reference PRISM scene", 2: "reference TRIS scene", 100: "random-spheres tri scene",
+               101: "100k-triangle mesh in the Cornell shell"}
 
 
 def log(msg):
     print("[bench] " + msg, file=sys.stderr, flush=True)
 
 
-def cpu_baseline(srt, scene, cam, width, height, depth, mode, budget_s=20.0, gpu_renderer=None):
-    """The oracle (kind "port") on all host cores, same scene/camera/size, reduced spp (rate is spp independent)."""
+def oracle_scene(srt, scene, mode):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_binding as O
-    cores = os.cpu_count() or 1
     osc = O.OracleScene(scene.triangles(), scene.materials(), scene.background())
     if mode == srt.BVH_REFERENCE:
         assert osc.build_reference(1984) == 1
     else:
         left, right, prim, _ = scene.bvh()
         assert osc.set_bvh(left, right, prim, 0) == 1
+    return osc
+
+
+def cpu_baseline(srt, scene, cam, width, height, depth, mode, budget_s=18.0, gpu_renderer=None):
+    """The oracle (kind "port") on all host cores, same scene/camera/size, reduced spp (rate is spp independent)."""
+    cores = os.cpu_count() or 1
+    osc = oracle_scene(srt, scene, mode)
     t0 = time.time()
     r = osc.render(cam, width, height, 1, depth, threads=cores)           # calibration pass: 1 spp
     dt1 = max(time.time() - t0, 1e-3)
@@ -68,6 +85,42 @@ def cpu_baseline(srt, scene, cam, width, height, depth, mode, budget_s=20.0, gpu
     return out
 
 
+def cfg1_single_thread(srt, budget_s=25.0):
+    """BASELINE.md CPU-baseline plan item 1: config 1 (reference CORNELL scene, 256x256, 16 spp, depth 8, reference BVH) on ONE
+    host thread, full size; wall seconds and Mray/s.  If the full run would not fit the budget it is cut to fewer spp and says so."""
+    scene = srt.Scene.builtin(srt.SCENE_CORNELL, 0).build_bvh(srt.BVH_REFERENCE, 1984)
+    W = H = 256
+    cam = scene.default_camera(W, H)
+    osc = oracle_scene(srt, scene, srt.BVH_REFERENCE)
+    t0 = time.time()
+    osc.render(cam, W, H, 1, 8, threads=1)
+    dt1 = max(time.time() - t0, 1e-3)
+    spp = 16 if 16 * dt1 <= budget_s else max(1, int(budget_s / dt1))
+    t0 = time.time()
+    r = osc.render(cam, W, H, spp, 8, threads=1)
+    dt = time.time() - t0
+    return {"wall_s": dt, "value": r["stats"]["rays"] / dt / 1e6, "unit": "Mray/s", "cores": 1, "kind": "port",
+            "sample": "CORNELL 256x256, %d spp%s, depth 8, reference BVH, 1 thread" % (spp, "" if spp == 16 else " (of 16: budget)")}
+
+
+def measure_hbm_copy_gbs(torch):
+    """Device-to-device copy rate of this GPU (the HBM figure is divided by a MEASURED peak): read + write bytes / s."""
+    n = 1 << 28                                    # 1 GiB of fp32 per buffer: far beyond the 256 MiB Infinity Cache
+    a = torch.empty(n, dtype=torch.float32, device="cuda").fill_(1.0)
+    b = torch.empty_like(a)
+    b.copy_(a)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(4):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 4
+    del a, b
+    return 2 * n * 4 / (ms * 1e-3) / 1e9
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -80,10 +133,8 @@ def main():
     ap.add_argument("--depth", type=int, default=16)
     ap.add_argument("--bvh", type=int, default=1)              # SRT_BVH_SAH for the synthetic scenes
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--rehearse-gloo", action="store_true",
-                    help="rehearsal of the N>1 path on ONE GPU: all ranks use cuda:0 and the gather goes through gloo/host (never used for reported numbers)")
-    ap.add_argument("--pmc-traffic-bytes", type=float, default=None,
-                    help="HBM bytes per launch from a separate rocprofv3 --pmc pass; default: profiles/r01/hbm_traffic.json when the workload matches")
+    ap.add_argument("--no-calibration", action="store_true", help="skip the issue-rate microkernel and the copy-rate measurement (profiling passes)")
+    ap.add_argument("--torch-gather", action="store_true", help="N > 1: gather through torch.distributed instead of the library's RCCL communicator")
     args = ap.parse_args()
 
     import torch
@@ -98,17 +149,12 @@ def main():
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
-    if args.rehearse_gloo:
-        local_rank = 0
     if local_rank >= torch.cuda.device_count():      # launcher restricted each rank's visible devices to its own GPU
         local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if args.rehearse_gloo:
-            dist.init_process_group(backend="gloo")
-        else:
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     import __graft_entry__
     srt = __graft_entry__._pkg()
@@ -125,47 +171,74 @@ def main():
     r.set_partition(rank, world)
     stream = torch.cuda.current_stream().cuda_stream
 
+    # ---- the exchange path: the library's own RCCL communicator (srt_comm_*, behind the C-ABI); torch.distributed only
+    # carries the 128-byte communicator id, the barriers and the statistics.  If the communicator cannot be formed the
+    # gather falls back to torch.distributed (same bytes, same xGMI links) and the JSON says so.
+    comm, gather_via = None, "none (1 GPU)"
+    if world > 1:
+        gather_via = "torch.distributed gather"
+        if not args.torch_gather:
+            try:
+                ident = [srt.Comm.unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(ident, src=0)
+                comm = srt.Comm.init_rank(r, ident[0], rank, world)
+                gather_via = "srt_render_frame_multi (ncclGather inside libsrt_hip.so)"
+            except Exception as e:      # noqa: BLE001 -- any failure here must not lose the measurement
+                log("rank %d: library communicator unavailable (%r); using torch.distributed for the gather" % (rank, e))
+                comm = None
+            ok = torch.tensor([1.0 if comm is not None else 0.0], device="cuda")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if float(ok[0]) < 0.5 and comm is not None:      # every rank or none
+                comm.close()
+                comm = None
+            if comm is None:
+                gather_via = "torch.distributed gather (library communicator unavailable)"
+
     # ---- V, T (node records / triangle tests per ray) from the instrumented kernel, outside the timed region
     r.init_device_params(W, H, 4, args.depth, 1984)
     r.set_count_traversal(True)
     r.render_chunk(W, H, 0, 0, stream)
     st = r.stats()
-    red_dev = "cpu" if args.rehearse_gloo else "cuda"
-    cnt = torch.tensor([st["rays"], st["node_visits"], st["tri_tests"], st["paths"]], dtype=torch.float64, device=red_dev)
+    cnt = torch.tensor([st["rays"], st["node_visits"], st["tri_tests"], st["paths"], st["util"][2]], dtype=torch.float64, device="cuda")
     if world > 1:
         dist.all_reduce(cnt)
-    rays_c, V_c, T_c, paths_c = [float(x) for x in cnt.tolist()]
+    rays_c, V_c, T_c, paths_c, nan_c = [float(x) for x in cnt.tolist()]
     V, T, rays_per_path = V_c / rays_c, T_c / rays_c, rays_c / paths_c
     b_ray = V * NODE_BYTES + T * TRI_BYTES + MAT_BYTES
     r.set_count_traversal(False)
 
-    r.init_device_params(W, H, args.spp, args.depth, 1984)
-    geom = dict(r.geom)
+    # ---- calibration of the roofs, outside the timed region (rank 0, N = 1) -------------------------------------------
+    calib, copy_gbs = None, None
+    if rank == 0 and world == 1 and not args.no_calibration:
+        calib = r.calibrate(0, 4, 40000)            # v_add_f32, 4 waves / SIMD, one workgroup per CU
+        copy_gbs = measure_hbm_copy_gbs(torch)
+        log("calibration: %.1f G wave-instr/s (%.3f / cycle / SIMD at %.2f GHz); copy %.0f GB/s" %
+            (calib["instr_per_s"] / 1e9, calib["instr_per_cycle_per_simd"], calib["clock_ghz"], copy_gbs))
 
-    local_tiles = None      # torch-owned staging tensor for the gather (multi-rank only)
+    r.init_device_params(W, H, args.spp, args.depth, 1984)
+
+    local_tiles = None      # torch-owned staging tensor for the torch.distributed gather
 
     def step():
         # one step = one complete frame: seed the per-pixel RNG streams (init_device_params, rendering.cu:320-335), render,
         # assemble the framebuffer on rank 0.  Every step therefore produces the same image (fb_checksum).
         nonlocal local_tiles
         r.init_device_params(W, H, args.spp, args.depth, 1984)
-        r.render_chunk(W, H, 0, 0, stream)
         if world == 1:
+            r.render_chunk(W, H, 0, 0, stream)
             r.scatter_tiles(None, stream)
+        elif comm is not None:
+            comm.render_frame(W, H, 0, 0)           # render + ONE ncclGather + scatter on rank 0, all enqueued by the library
+            comm.synchronize()
         else:
+            r.render_chunk(W, H, 0, 0, stream)
             if local_tiles is None:
                 _, _, _, tp = r.tile_buffer()
                 local_tiles = torch.empty((tp, tiles.PLANES, tiles.LANES), dtype=torch.float32, device="cuda")
             r.copy_tile_buffer(local_tiles.data_ptr(), stream)        # stream-ordered D2D into the tensor RCCL sends
-            if args.rehearse_gloo:
-                gh = tiles.gather_tiles(local_tiles.cpu(), rank, world)
-                g = gh.cuda() if rank == 0 else None
-            else:
-                g = tiles.gather_tiles(local_tiles, rank, world)      # the single collective of the path (RCCL over xGMI)
+            g = tiles.gather_tiles(local_tiles, rank, world)          # the single collective of the path
             if rank == 0:
                 r.scatter_tiles(g.data_ptr(), stream)
-                torch.cuda.current_stream().synchronize() if args.rehearse_gloo else None
-        return r
 
     def barrier():
         if world > 1:
@@ -185,7 +258,7 @@ def main():
     for k in range(args.steps):
         ts = time.time()
         step()
-        # per-step kernel time from the HIP events the library records on `stream`; reading it waits for the
+        # per-step kernel time from the HIP events the library records on the launch stream; reading it waits for the
         # kernel only, and is inside the timed region on purpose (it costs one event sync).
         kernel_ms.append(r.last_kernel_ms())
         rays_local += r.stats()["rays"]
@@ -194,7 +267,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
 
-    tot = torch.tensor([float(rays_local), elapsed, sum(kernel_ms) / max(len(kernel_ms), 1)], dtype=torch.float64, device=red_dev)
+    tot = torch.tensor([float(rays_local), elapsed, sum(kernel_ms) / max(len(kernel_ms), 1)], dtype=torch.float64, device="cuda")
     if world > 1:
         rays_t = tot[0:1].clone(); dist.all_reduce(rays_t)
         mx = tot[1:3].clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
@@ -204,42 +277,70 @@ def main():
 
     if rank == 0:
         steps = max(args.steps, 1)
-        traffic = args.pmc_traffic_bytes
-        if traffic is None and world == 1 and (args.scene, W, H, args.spp, args.depth, args.bvh) == (100, 1920, 1080, 1024, 16, 1):
-            try:      # measured once with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on this exact workload
-                traffic = json.load(open(os.path.join(ROOT, "profiles", "r01", "hbm_traffic.json")))["hbm_bytes_per_launch"]
-            except Exception:
-                traffic = None
+        headline = world == 1 and (args.scene, W, H, args.spp, args.depth, args.bvh) == (100, 1920, 1080, 1024, 16, 1)
         mray = total_rays / elapsed / 1e6
         rays_per_launch_rank0 = rays_local / steps
-        achieved = rays_per_launch_rank0 * b_ray / (kms * 1e-3) / 1e9            # GB/s, dominant kernel on this rank
+        # ---- roofline of the dominant kernel (render_kernel) on this rank -------------------------------------------
+        imported = None
+        try:
+            imported = json.load(open(LANE_OPS_FILE))
+        except Exception:      # noqa: BLE001
+            imported = None
+        entry = (imported or {}).get("scene_%d" % args.scene)
+        roof = {"bound": "valu-issue", "achieved": None, "peak": None, "unit": "G lane-op/s", "frac": None, "traffic": None}
+        if entry is not None:
+            lane_ops_per_ray = entry["lane_ops_per_ray"]
+            roof["achieved"] = rays_per_launch_rank0 * lane_ops_per_ray / (kms * 1e-3) / 1e9
+            roof["achieved_source"] = ("useful VALU lane-ops per ray = %.1f (SQ_THREAD_CYCLES_VALU / rays, rocprofv3 --pmc pass of kernel %s, "
+                                       "IMPORTED from profiles/r02/lane_ops_per_ray.json) x %.4g rays per launch / %.2f ms render-kernel time, both measured in this run"
+                                       % (lane_ops_per_ray, entry.get("kernel", "?"), rays_per_launch_rank0, kms))
+            roof["lanes_per_valu_instruction"] = entry.get("lanes_per_valu_instruction")
+            roof["wave_time_split"] = entry.get("wave_time_split")
+            if entry.get("hbm_bytes_per_launch_1024spp") is not None and headline:
+                roof["traffic"] = entry["hbm_bytes_per_launch_1024spp"]
+                roof["traffic_source"] = "IMPORTED from profiles/r02 (FETCH_SIZE + WRITE_SIZE, separate --pmc passes of this workload), not measured in this run"
+        if calib is not None:
+            roof["peak"] = calib["instr_per_s"] * 64 / 1e9
+            roof["peak_source"] = ("measured in this run: srt_calibrate kind 0 (independent v_add_f32, 4 waves/SIMD, all %d CUs) = %.1f G wave-instr/s "
+                                   "(%.3f per cycle per SIMD at %.2f GHz) x 64 lanes" % (calib["n_cu"], calib["instr_per_s"] / 1e9,
+                                                                                       calib["instr_per_cycle_per_simd"], calib["clock_ghz"]))
+        if roof["achieved"] is not None and roof["peak"]:
+            roof["frac"] = roof["achieved"] / roof["peak"]
+        hbm_alg = rays_per_launch_rank0 * b_ray / (kms * 1e-3) / 1e9
+        roof["hbm"] = {"algorithmic_GBs": hbm_alg, "algorithmic_bytes_per_ray": b_ray, "measured_copy_peak_GBs": copy_gbs, "spec_peak_GBs": HBM_SPEC_GBS,
+                       "frac_of_measured_peak": (hbm_alg / copy_gbs) if copy_gbs else None,
+                       "note": "SURVEY 8(d) figure V*64 + T*48 + 56 bytes per ray; these bytes are served by LDS / L2 (the whole inner tree is LDS "
+                               "resident), HBM is not the roof -- a value above 1 says exactly that"}
         fb = r.read_fb()                       # outside the timed region: image checksum, identical for every N
         checksum = int(sum(int(p.astype("int64").sum()) for p in fb))
         out = {
             "metric": "Mray/s", "value": mray, "unit": "Mray/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s (%d tris, %d BVH nodes, %s tree), %dx%d, %d spp, depth %d" %
-                                   ({0: "reference CORNELL scene", 1: "reference PRISM scene", 2: "reference TRIS scene", 100: "random-spheres tri scene",
-                                     101: "100k-triangle mesh in the Cornell shell"}.get(args.scene, "scene %d" % args.scene), scene.n_tris, scene.n_nodes, "SAH" if args.bvh == 1 else "reference", W, H, args.spp, args.depth),
-                       "scene_id": args.scene, "tiles": "8x8 px per wave, rank = tile % n_gpus", "gather": "1 RCCL gather of compact tiles"},
+            "config": {"workload": "%s (%d tris, %d BVH nodes), %dx%d, %d spp, depth %d" %
+                                   (SCENE_NAMES.get(args.scene, "scene %d" % args.scene), scene.n_tris, scene.n_nodes, W, H, args.spp, args.depth),
+                       "scene_id": args.scene,
+                       "bvh": "SAH-128, one triangle per leaf, children ordered by distance to the scene's default camera" if args.bvh == 1 else "reference builder (bvh/bvh.cu:206-346)",
+                       "nan_direction_rays": "%.2f %% of the counted rays have a NaN direction (Sellmeier quirk Q1) and are answered 'miss' without walking the tree" % (100.0 * nan_c / rays_c),
+                       "tiles": "8x8 px per wave, rank = tile % n_gpus", "gather": gather_via},
             "mpath_per_s": (W * H * args.spp * steps) / elapsed / 1e6,
             "rays_per_path": rays_per_path, "node_records_per_ray_V": V, "tri_tests_per_ray_T": T, "algorithmic_bytes_per_ray": b_ray,
             "kernel_ms_per_step": kms, "fb_checksum": checksum,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic,
-                         "note": "achieved = algorithmic bytes (V*64 + T*48 + 56 per ray) / render-kernel time. The scene is "
-                                 "LDS/L2-resident, so these bytes never reach HBM (traffic = measured HBM bytes per launch, "
-                                 "profiles/r01/hbm_traffic.json): the kernel is bound by VALU issue (96 % busy at 26 of 64 lanes per instruction, "
-                                 "profiles/r01/v8_pmc_summary_64spp.txt), a frac above 1 is possible"},
+            "roofline": roof,
         }
         if not args.no_cpu_baseline and world == 1:     # the CPU baseline is reported at N=1 only
             try:
                 out["cpu_baseline"] = cpu_baseline(srt, scene, cam, W, H, args.depth, args.bvh, gpu_renderer=r)
-            except Exception as e:   # the checker is optional for the measurement itself
+            except Exception as e:   # noqa: BLE001 -- the checker is optional for the measurement itself
                 out["cpu_baseline"] = {"value": None, "unit": "Mray/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %r" % (e,)}
+            try:
+                out["cpu_baseline"]["cfg1_single_thread"] = cfg1_single_thread(srt)
+            except Exception as e:   # noqa: BLE001
+                out["cpu_baseline"]["cfg1_single_thread"] = {"value": None, "sample": "failed: %r" % (e,)}
         print(json.dumps(out), flush=True)
 
+    if comm is not None:
+        comm.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

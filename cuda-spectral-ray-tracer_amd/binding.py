@@ -38,7 +38,7 @@ class CameraData(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("paths", C.c_uint64), ("node_visits", C.c_uint64), ("tri_tests", C.c_uint64),
-                ("box_tests", C.c_uint64), ("util", C.c_uint64 * 9), ("reserved", C.c_uint64 * 2)]
+                ("box_tests", C.c_uint64), ("util", C.c_uint64 * 9), ("reserved", C.c_uint64 * 2), ("shade", C.c_uint64 * 4)]
 
 
 class Calibration(C.Structure):

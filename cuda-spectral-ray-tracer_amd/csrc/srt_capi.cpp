@@ -396,7 +396,8 @@ int srt_get_stats(srt_ctx *c, srt_stats *out) {
     memset(out, 0, sizeof(*out));
     out->rays = h[0]; out->node_visits = h[1]; out->tri_tests = h[2]; out->box_tests = h[3];
     for (int k = 0; k < 9; k++) out->util[k] = h[4 + k];
-    out->reserved[0] = h[13]; out->reserved[1] = h[14];   // instrumented: max node visits / max rays of any single pixel
+    out->reserved[0] = h[13]; out->reserved[1] = h[14];
+    for (int k = 0; k < 4; k++) out->shade[k] = h[15 + k];   // instrumented: max node visits / max rays of any single pixel
     // paths = spp * pixels owned by this rank
     uint64_t pixels = 0;
     for (uint32_t t = c->rank; t < c->n_tiles; t += c->world) {

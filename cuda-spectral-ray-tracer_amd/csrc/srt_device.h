@@ -154,7 +154,7 @@ __device__ __forceinline__ float sellmeier_index(float b0, float b1, float b2, f
 __device__ __forceinline__ float reflectance(float cosine, float ref_idx) {
     float r0 = (1.0f - ref_idx) / (1.0f + ref_idx);
     r0 = r0 * r0;
-    return r0 + (1.0f - r0) * dev_powf(1.0f - cosine, 5.0f);
+    return r0 + (1.0f - r0) * srt_pow5f(1.0f - cosine);   // pow(1 - cosine, 5.0f), material.cu:48 (DESIGN D3)
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -8,7 +8,7 @@ namespace srt {
 
 constexpr int kTilePlanes = 9;      // quantised rgb | unquantised sRGB | XYZ sums
 constexpr int kTileLanes = 64;      // one wave = one 8x8 pixel tile
-constexpr int kCounters = 16;       // rays, node_visits, tri_tests, box_tests, utilisation counters (instrumented build)
+constexpr int kCounters = 24;       // rays, node_visits, tri_tests, box_tests, utilisation counters (instrumented build)
 
 // Kernel arguments of one render launch.  All pointers are device pointers.
 struct RenderParams {

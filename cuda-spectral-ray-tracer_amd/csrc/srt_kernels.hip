@@ -192,15 +192,19 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
     if (COUNT) t_mark = __builtin_amdgcn_s_memtime();
     uint32_t cur_tile_local = 0, pixel_iters0 = 0;   // probe / instrumented builds
     uint32_t pixel_rays0 = 0, max_pix_iters = 0, max_pix_rays = 0;
+    uint32_t w_shade_passes = 0, l_shade = 0, l_cam = 0, w_reject_iters = 0;   // instrumented build: shading-phase occupancy
 
     for (;;) {
         // parked lanes wake up when no lane of the wave holds a pixel any more
         if (__ballot(have_pixel) == 0ull) parked = false;
         // =========================== shading phase ===========================================================
         // every lane that is neither traversing nor dead nor parked goes through: shade -> path end -> pixel switch ->
-        // camera ray -> start traversal.  The loop repeats only in corner cases (bounce_limit 0, leaf-root BVH).
-        while (__ballot(!dead && !parked && tv.node < 0) != 0ull) {
+        // camera ray -> start traversal.  ONE pass per turn of the outer loop: in the corner cases where a pass leaves lanes
+        // without a query (bounce_limit 0, leaf-root BVH, NaN directions) the traversal phase below finds nothing to do and
+        // the outer loop comes back here.
+        if (__ballot(!dead && !parked && tv.node < 0) != 0ull) {
             bool end_path = false, begin_trav = false;
+            if (COUNT) { w_shade_passes++; l_shade += (uint32_t)__popcll(__ballot(!dead && tv.node == kTravDone)); }
             float xyz_x = 0.0f, xyz_y = 0.0f, xyz_z = 0.0f;      // XYZ of a path that ends in this pass
 
             // ---- S1: shade a finished closest-hit query: one iteration of ray_bounce's loop (rendering.cu:22-36)
@@ -398,6 +402,7 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
             }
 
             // ---- S4: new camera ray: renderer::get_ray (rendering.cu:66-87) ----------------------------------------
+            if (COUNT) l_cam += (uint32_t)__popcll(__ballot(!dead && tv.node < 0 && !have_path && !begin_trav && have_pixel && sample < spp));
             if (!dead && tv.node < 0 && !have_path && !begin_trav && have_pixel && sample < spp) {
                 float px = -0.5f + rng_uniform(rs);                       // pixel_sample_square, :49-56
                 float py = -0.5f + rng_uniform(rs);
@@ -523,6 +528,10 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
             if (lane == 0) {
                 atomicAdd(&P.counters[11], t_inner);
                 atomicAdd(&P.counters[12], t_fringe);
+                atomicAdd(&P.counters[15], (unsigned long long)w_shade_passes);
+                atomicAdd(&P.counters[16], (unsigned long long)l_shade);
+                atomicAdd(&P.counters[17], (unsigned long long)l_cam);
+                atomicAdd(&P.counters[18], (unsigned long long)w_reject_iters);
             }
         }
     }
@@ -724,6 +733,7 @@ __global__ void op_sweep_kernel(int which, const float *a, const float *b, uint3
     case 14: { f2 a2 = mk2(x, y), b2 = mk2(y, x); f2 c2 = a2 * b2; r = c2.x; if (k & 1) r = c2.y; } break;          // v_pk_mul_f32
     case 15: { f2 a2 = mk2(x, y), b2 = mk2(y, x * 0.5f); f2 c2 = a2 + b2; r = (k & 1) ? c2.y : c2.x; } break;    // v_pk_add_f32
     case 16: { f2 a2 = mk2(x, y), b2 = mk2(y, x); f2 c2 = (a2 - b2) * x - a2 * b2; r = (k & 1) ? c2.y : c2.x; } break;
+    case 17: r = srt_pow5f(x); break;                  // must equal dev_powf(x, 5)
     default: r = 0.f;
     }
     out[k] = r;

@@ -81,5 +81,17 @@ SRT_HD float srt_powf(float xf, float yf) {
     return (float)(q * two_k);
 }
 
+// srt_powf(x, 5.0f) for the Schlick call site (materials/material.cu:48), inlined: the same special cases in the same
+// order and the same fp64 products as the y == 5 branch above, so the bits are srt_powf's (checked on the device by the
+// op sweep, op 17) without the call and the general branch's code.
+SRT_HD float srt_pow5f(float xf) {
+    if (xf != xf) return xf + 5.0f;
+    if (xf == 1.0f) return 1.0f;
+    if (xf == 0.0f) return 0.0f;
+    if (xf < 0.0f) return __builtin_nanf("");
+    if (__builtin_isinf(xf)) return __builtin_inff();
+    const double x = (double)xf, x2 = x * x;
+    return (float)((x2 * x2) * x);
+}
 
 }  // namespace srt

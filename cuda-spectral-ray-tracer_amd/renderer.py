@@ -112,6 +112,7 @@ class Renderer:
         self._ck(B.lib().srt_get_stats(self._h, C.byref(st)))
         d = {k: getattr(st, k) for k in ("rays", "paths", "node_visits", "tri_tests", "box_tests")}
         d["util"] = list(st.util)
+        d["shade"] = list(st.shade)
         d["max_pixel_node_visits"], d["max_pixel_rays"] = st.reserved[0], st.reserved[1]
         return d
 

@@ -85,7 +85,10 @@ typedef struct {
      * inner steps.  SIMD utilisation of traversal =
      * node_visits / (64 * util[0]).  node_visits / tri_tests / box_tests count the work actually done. */
     uint64_t util[9];   /* [6..8]: wave cycles spent in the shading phase / inner steps / fringe steps */
-    uint64_t reserved[2];
+    uint64_t reserved[2];   /* instrumented: max node visits / max rays of any single pixel */
+    /* instrumented kernel only: [0] shading passes (wave level), [1] lanes that shaded a finished query in them,
+     * [2] lanes that generated a camera ray, [3] wave-level iterations of the unit-sphere rejection loop */
+    uint64_t shade[4];
 } srt_stats;
 
 typedef struct srt_scene srt_scene;   /* host-side flattened scene (replaces scene_manager's device heap) */

@@ -69,6 +69,9 @@ def test_powf_matches_oracle_and_libm(gpu, orc):
         # rounding tie far more often than a generic real does.
         lib = np.power(x.astype(np.float64), np.float64(np.float32(y))).astype(np.float32)
         assert int(np.sum(bits(got) != bits(lib))) <= (16 if y == 2.0 else 2), y
+    # the inlined Schlick power (srt_pow5f) is srt_powf(x, 5) bit for bit, special operands included
+    xs = np.concatenate([x, _special_floats(rng, 4096)]).astype(np.float32)
+    assert _same(gpu.op_sweep(17, xs, xs), gpu.op_sweep(8, xs, np.full_like(xs, np.float32(5.0))))
 
 
 SCENES = [

@@ -13,6 +13,15 @@ PKG = os.path.join(ROOT, "cuda-spectral-ray-tracer_amd")
 EXE = os.path.join(ROOT, "tests", "cpp", "_build", "host_api_demo")
 
 
+def demo_is_stale():
+    """The demo embeds the struct layouts of include/srt_c_api.h: rebuild whenever a header or the library is newer."""
+    if not os.path.exists(EXE):
+        return True
+    deps = [os.path.join(ROOT, "include", "srt_c_api.h"), os.path.join(PKG, "csrc", "host_api.hpp"), os.path.join(PKG, "libsrt_hip.so"),
+            os.path.join(ROOT, "tests", "cpp", "host_api_demo.cpp")]
+    return any(os.path.getmtime(d) > os.path.getmtime(EXE) for d in deps if os.path.exists(d))
+
+
 def build_demo():
     os.makedirs(os.path.dirname(EXE), exist_ok=True)
     subprocess.check_call(["g++", "-std=c++20", "-O1", "-o", EXE, os.path.join(ROOT, "tests", "cpp", "host_api_demo.cpp"),
@@ -27,7 +36,7 @@ def test_cpp_mirror_compiles_and_links(srt):
 @pytest.mark.gpu
 @pytest.mark.parametrize("chunk,spp", [((0, 0), 6), ((40, 40), 6), ((40, 40), 12)])   # 12 spp: the cost probe + ordered queue run per chunk
 def test_render_manager_matches_oracle(srt, orc, tmp_path, chunk, spp):
-    if not os.path.exists(EXE):
+    if demo_is_stale():
         build_demo()
     W, H, depth = 72, 56, 8
     out = str(tmp_path / "img.bin")
