@@ -17,7 +17,7 @@ struct srt_ctx {
     int device = 0;
     std::string err;
     // scene images in HBM
-    float *d_nodes = nullptr, *d_fringe = nullptr, *d_tris = nullptr, *d_mat_sd = nullptr, *d_mat_par = nullptr, *d_bg = nullptr, *d_cmf = nullptr;
+    float *d_nodes = nullptr, *d_fringe = nullptr, *d_tris = nullptr, *d_mat_sd = nullptr, *d_mat_par = nullptr, *d_shade = nullptr, *d_cmf = nullptr;
     int root_ref = 0, stack_depth = 1, n_inner = 0, n_records = 0;
     uint32_t n_tris = 0;
     uint32_t n_materials = 0;
@@ -85,7 +85,7 @@ void fill_params(const srt_ctx *c, RenderParams &p) {
     memset(&p, 0, sizeof(p));
     p.nodes = (const float4 *)c->d_nodes; p.fringe = (const float4 *)c->d_fringe; p.tris = (const float4 *)c->d_tris;
     p.mat_sd = (const float2 *)c->d_mat_sd; p.mat_par = (const float4 *)c->d_mat_par;
-    p.bg_sd = (const float2 *)c->d_bg; p.cmf = (const float4 *)c->d_cmf;
+    p.shade = (const float4 *)c->d_shade; p.cmf = (const float4 *)c->d_cmf;
     p.root_ref = c->root_ref; p.stack_depth = c->stack_depth; p.n_materials = c->n_materials;
     p.n_inner = c->n_inner; p.n_cached = 0;   // n_cached is set by the launcher
     p.n_tris = c->n_tris; p.n_records = c->n_records;
@@ -147,7 +147,7 @@ void srt_destroy(srt_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    void *bufs[] = {c->d_nodes, c->d_fringe, c->d_tris, c->d_mat_sd, c->d_mat_par, c->d_bg, c->d_cmf, c->d_rng, c->d_fb, c->d_tiles, c->d_counters, c->d_tile_cost, c->d_tile_order, c->d_rowmajor};
+    void *bufs[] = {c->d_nodes, c->d_fringe, c->d_tris, c->d_mat_sd, c->d_mat_par, c->d_shade, c->d_cmf, c->d_rng, c->d_fb, c->d_tiles, c->d_counters, c->d_tile_cost, c->d_tile_order, c->d_rowmajor};
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -170,7 +170,7 @@ int srt_upload_scene(srt_ctx *c, const srt_scene *s) {
     if ((rc = upload(c, &c->d_tris, f.tris)) != SRT_OK) return rc;
     if ((rc = upload(c, &c->d_mat_sd, f.mat_sd)) != SRT_OK) return rc;
     if ((rc = upload(c, &c->d_mat_par, f.mat_par)) != SRT_OK) return rc;
-    if ((rc = upload(c, &c->d_bg, f.bg_sd)) != SRT_OK) return rc;
+    if ((rc = upload(c, &c->d_shade, f.shade)) != SRT_OK) return rc;
     c->root_ref = f.root_ref; c->stack_depth = f.stack_depth; c->n_materials = (uint32_t)s->mats.size();
     c->n_inner = f.n_inner; c->n_records = f.n_records; c->n_tris = (uint32_t)s->raw.size();
     c->scene_ready = true;

@@ -280,6 +280,11 @@ __device__ __forceinline__ buf_rsrc make_rsrc(const void *base, uint32_t bytes) 
 __device__ __forceinline__ f4v buf_load16(buf_rsrc r, uint32_t byte_offset) {
     return as_f4v(__builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_offset, 0, 0));
 }
+typedef unsigned int u2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float2 buf_load8(buf_rsrc r, uint32_t byte_offset) {
+    const u2v v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)byte_offset, 0, 0);
+    return make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
+}
 
 // Node record, 64 B: three axis planes (lo_L, lo_R, hi_L, hi_R) for x, y, z -- the boxes of the left / right child side
 // by side, so that one packed operation serves both children -- then lref, rref (child references: >= 0 record index,

@@ -416,7 +416,8 @@ int flatten_scene(const srt_scene &s, FlatScene &out) {
         for (int k = 0; k < 96; k++) { dst[2 * k] = 0.f; dst[2 * k + 1] = 0.f; }
         for (int k = 0; k < SRT_N_CIE_SAMPLES - 1; k++) { dst[2 * k] = sd[k]; dst[2 * k + 1] = sd[k + 1]; }
     };
-    out.mat_sd.assign(192 * std::max<size_t>(n_mats, 1), 0.f);
+    // (table n_mats = the background spectrum: a miss multiplies it into the path exactly like a hit multiplies its material's)
+    out.mat_sd.assign(192 * (n_mats + 1), 0.f);
     out.mat_par.assign(8 * std::max<size_t>(n_mats, 1), 0.f);
     for (size_t m = 0; m < n_mats; m++) {
         const srt_material &mt = s.mats[m];
@@ -426,8 +427,18 @@ int flatten_scene(const srt_scene &s, FlatScene &out) {
         o[2] = mt.sellmeier_B[0]; o[3] = mt.sellmeier_B[1]; o[4] = mt.sellmeier_B[2];
         o[5] = mt.sellmeier_C[0]; o[6] = mt.sellmeier_C[1]; o[7] = mt.sellmeier_C[2];
     }
-    out.bg_sd.assign(192, 0.f);
-    pairs(s.background, out.bg_sd.data());
+    pairs(s.background, &out.mat_sd[192 * n_mats]);
+    // shading records, 48 B per triangle: { n.x n.y n.z bits(mat) } { bits(type) fuzz B0 B1 } { B2 C0 C1 C2 } -- everything
+    // material::scatter needs about the hit in ONE round of loads (instead of triangle -> material index -> material)
+    out.shade.assign(12 * std::max<size_t>(n_tris, 1), 0.f);
+    for (size_t k = 0; k < n_tris; k++) {
+        const srt_material &mt = s.mats[s.raw[k].mat_index];
+        float *o = &out.shade[12 * k];
+        o[0] = s.rec[k].n[0]; o[1] = s.rec[k].n[1]; o[2] = s.rec[k].n[2]; o[3] = bits_to_float(s.raw[k].mat_index);
+        o[4] = bits_to_float(mt.material_type); o[5] = mt.reflection_fuzz;
+        o[6] = mt.sellmeier_B[0]; o[7] = mt.sellmeier_B[1]; o[8] = mt.sellmeier_B[2];
+        o[9] = mt.sellmeier_C[0]; o[10] = mt.sellmeier_C[1]; o[11] = mt.sellmeier_C[2];
+    }
     return SRT_OK;
 }
 

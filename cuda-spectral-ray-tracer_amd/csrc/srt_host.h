@@ -76,9 +76,9 @@ struct FlatScene {
     std::vector<float> nodes;    // 16 floats per INNER record (both children internal)
     std::vector<float> fringe;   // 24 floats per FRINGE record (a leaf child; triangle data inline, (left, right) pairs), record index - n_inner
     std::vector<float> tris;     // 12 floats per triangle
-    std::vector<float> mat_sd;   // 192 floats per material
+    std::vector<float> mat_sd;   // 192 floats per material, then 192 for the background (table index n_materials)
+    std::vector<float> shade;    // 12 floats per triangle: normal, material index, material scalars (shading record)
     std::vector<float> mat_par;  // 8 floats per material
-    std::vector<float> bg_sd;    // 192 floats
     int root_ref = 0;
     int stack_depth = 1;
     int n_inner = 0;             // records [0, n_inner) have two internal children (BFS order); the rest have a leaf child

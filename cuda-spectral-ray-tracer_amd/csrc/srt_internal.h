@@ -16,9 +16,9 @@ struct RenderParams {
     const float4 *nodes;       // 4 float4 per INNER record (records [0, n_inner))
     const float4 *fringe;      // 6 float4 per FRINGE record (records [n_inner, n_records)), triangle data inline
     const float4 *tris;        // 3 float4 per triangle
-    const float2 *mat_sd;      // per material 96 pairs (94 used): (sd[k], sd[k+1])
+    const float2 *mat_sd;      // per material 96 pairs (94 used): (sd[k], sd[k+1]); table n_materials = the background
+    const float4 *shade;       // 3 float4 per triangle: {n, bits(mat)} {bits(type), fuzz, B0, B1} {B2, C0, C1, C2}
     const float4 *mat_par;     // per material 2 float4: {bits(type), fuzz, B0, B1}, {B2, C0, C1, C2}
-    const float2 *bg_sd;       // 96 pairs (94 used) of the background spectrum
     const float4 *cmf;         // 96 rows (95 used): { x_bar, y_bar, z_bar, D65n }
     int root_ref;              // >= 0 record index, < 0: ~triangle (single-leaf tree)
     int stack_depth;           // LDS stack entries per lane

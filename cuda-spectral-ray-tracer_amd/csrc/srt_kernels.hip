@@ -159,6 +159,8 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
     ns.lds_q0 = (lds_cf4 *)s_q0; ns.lds_q1 = (lds_cf4 *)s_q1; ns.lds_q2 = (lds_cf4 *)s_q2;
     ns.lds_r0 = (lds_cu32 *)s_r0; ns.lds_r1 = (lds_cu32 *)s_r1;
     ns.n_cached = P.n_cached;
+    const buf_rsrc shade_rsrc = make_rsrc(P.shade, P.n_tris * 48u);
+    const buf_rsrc sd_rsrc = make_rsrc(P.mat_sd, (P.n_materials + 1u) * 768u);
     const uint32_t spp = P.spp;
     StackRef my_stack;
     {
@@ -213,24 +215,23 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
                 float wl[kWavelengths];
                 hero_expand(hero, wl);
                 // the spectrum this segment multiplies into the path: the background on a miss (rendering.cu:24-27), the hit
-                // material's reflectance otherwise (material.cu:95) -- one look-up site for both
-                const float2 *sd = P.bg_sd;
+                // material's reflectance otherwise (material.cu:95) -- one look-up site for both: table n_materials is the background
+                uint32_t sd_table = P.n_materials;
                 bool was_hit = false, hit_scattered = false;
                 if (tv.hit < 0) {
                     end_path = true;        // miss: r.mul_spectrum(background) and stop
                 } else {
-                    // rebuild the hit record from (t, triangle): tri::hit tail (tri.cu:36-39) + set_face_normal
-                    const int tri = tv.hit;
-                    const float4 ta = P.tris[3 * tri + 0];
-                    const float4 tc = P.tris[3 * tri + 2];
-                    const V3 n_geo = mk(ta.x, ta.y, ta.z);
+                    // rebuild the hit record from (t, triangle): tri::hit tail (tri.cu:36-39) + set_face_normal.  ONE round of
+                    // loads: the triangle's shading record carries the normal, the material index and the material scalars.
+                    const uint32_t srec = (uint32_t)tv.hit * 48u;
+                    const f4v s0 = buf_load16(shade_rsrc, srec), s1 = buf_load16(shade_rsrc, srec + 16u), s2 = buf_load16(shade_rsrc, srec + 32u);
+                    const V3 n_geo = mk(s0.x, s0.y, s0.z);
                     const V3 hp = ro + tv.c * rd;                                          // ray::at, ray.cuh:31-34
                     const bool front_face = dot(rd, n_geo) < 0;                            // hit_record.cuh:41
                     const V3 n = front_face ? n_geo : -n_geo;
-                    const uint32_t mat = __float_as_uint(tc.z) >> 8;
-                    const float4 mp0 = P.mat_par[2 * mat + 0];
-                    const float4 mp1 = P.mat_par[2 * mat + 1];
-                    const uint32_t mtype = __float_as_uint(mp0.x);
+                    const uint32_t mat = __float_as_uint(s0.w);
+                    const uint32_t mtype = __float_as_uint(s1.x);
+                    const float fuzz = s1.y;
 
                     // material::scatter (materials/material.cu:55-100)
                     V3 scatter_direction = mk(0.f, 0.f, 0.f);
@@ -240,7 +241,7 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
                     if (mtype == 4u) {                                                      // EMISSIVE, :83-86
                         did_scatter = false;
                     } else if (mtype == 2u) {                                               // DIELECTRIC, :73-80
-                        float ir = sellmeier_index(mp0.z, mp0.w, mp1.x, mp1.y, mp1.z, mp1.w, wl[0]);
+                        float ir = sellmeier_index(s1.z, s1.w, s2.x, s2.y, s2.z, s2.w, wl[0]);
                         // refraction_scatter, :102-136
                         float refraction_ratio = front_face ? (1.0f / ir) : ir;
                         float cos_theta = fminf(dot(-unit_in, n), 1.0f);
@@ -260,7 +261,7 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
                         const V3 ruv = unit_vector(random_in_unit_sphere(rs));             // vec3.cuh:221-227
                         if (mtype == 1u) {
                             V3 reflected = reflect(unit_in, n);                            // reflection_scatter, :22-37
-                            scatter_direction = reflected + mp0.y * ruv;
+                            scatter_direction = reflected + fuzz * ruv;
                             did_scatter = dot(scatter_direction, n) > 0;
                             if (!did_scatter) valid = 0;
                         } else {
@@ -268,31 +269,46 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
                             if (near_zero(scatter_direction)) scatter_direction = n;
                         }
                     }
-                    sd = P.mat_sd + (size_t)mat * 96u;
+                    sd_table = mat;
                     ro = hp + (eps_sign * kEpsilon) * n;                                    // :96 (Q9)
                     rd = scatter_direction;                                                 // :97
                     hit_scattered = did_scatter;
                     was_hit = true;
                 }
                 // r_in.mul_spectrum(spectral_distribution) (:95), after valid_wavelengths was updated (Q8).  A path that ends
-                // here (miss, or no scattered ray) is converted in the same loop: dev_spectrum_to_XYZ (color.cu:88-104) needs
+                // here (miss, or no scattered ray) is converted in the same pass: dev_spectrum_to_XYZ (color.cu:88-104) needs
                 // the same interpolation coordinates.  (A path that ends because the bounce limit is reached contributes
                 // nothing: valid_wavelengths = 0, rendering.cu:38.)
+                //
+                // All seven look-ups are issued together and the products are unconditional: power[k] for k >= valid is dead
+                // (valid only shrinks inside a path and a new path resets all seven), so multiplying it does no harm, while a
+                // per-wavelength `if (k < valid)` would put seven dependent memory round trips one after the other.
                 const bool ends_here = !was_hit || !hit_scattered;
                 const float delta_lambda = (kLambdaMax - kLambdaMin) / (float)kWavelengths;
+                const uint32_t sd_base = sd_table * 768u;
+                int off[kWavelengths];
+                float wgt[kWavelengths];
+                float2 sp[kWavelengths];
 #pragma unroll
                 for (int k = 0; k < kWavelengths; k++) {
-                    if ((uint32_t)k < valid) {
-                        int off; float w;
-                        interp_coords(wl[k], off, w);
-                        pw[k] *= interp_pair(sd[off], w);
-                        if (ends_here) {
-                            const float4 r0 = s_cmf[off], r1 = s_cmf[off + 1];
-                            const float power = pw[k];
-                            xyz_x += ((1.0f - w) * r0.x + w * r1.x) * power * delta_lambda;
-                            xyz_y += ((1.0f - w) * r0.y + w * r1.y) * power * delta_lambda;
-                            xyz_z += ((1.0f - w) * r0.z + w * r1.z) * power * delta_lambda;
-                        }
+                    interp_coords(wl[k], off[k], wgt[k]);
+                    sp[k] = buf_load8(sd_rsrc, sd_base + (uint32_t)off[k] * 8u);
+                }
+#pragma unroll
+                for (int k = 0; k < kWavelengths; k++) pw[k] *= interp_pair(sp[k], wgt[k]);
+                if (ends_here) {
+#pragma unroll
+                    for (int k = 0; k < kWavelengths; k++) {
+                        const float4 r0 = s_cmf[off[k]], r1 = s_cmf[off[k] + 1];
+                        const float w = wgt[k], power = pw[k];
+                        const float tx_ = ((1.0f - w) * r0.x + w * r1.x) * power * delta_lambda;
+                        const float ty_ = ((1.0f - w) * r0.y + w * r1.y) * power * delta_lambda;
+                        const float tz_ = ((1.0f - w) * r0.z + w * r1.z) * power * delta_lambda;
+                        // the reference sums the first `valid` terms; the others are replaced by +0, which leaves a sum unchanged
+                        const bool live = (uint32_t)k < valid;
+                        xyz_x += live ? tx_ : 0.0f;
+                        xyz_y += live ? ty_ : 0.0f;
+                        xyz_z += live ? tz_ : 0.0f;
                     }
                 }
                 if (was_hit) {
