@@ -14,6 +14,7 @@
 #pragma once
 #include <stdint.h>
 
+#include <atomic>
 #include <cmath>
 #include <iostream>
 #include <semaphore>
@@ -140,24 +141,45 @@ private:
     std::string res_msg;
 };
 
-// rendering/rendering.cuh:39-155
+// rendering/rendering.cuh:39-155.  One GPU (srt_ctx) or, when several devices are given, a communicator over them
+// (srt_comm: the chunk's 8x8-pixel tiles are interleaved over the GPUs, one RCCL gather brings them to the first device,
+// whose context then answers getDevFB* / srt_read_fb exactly like the single-GPU renderer).
 class renderer {
 public:
     renderer() {}
     renderer(const srt_scene *scene, uint _samples_per_pixel, const srt_camera_data &cam, uint _bounce_limit, int device = 0)
         : samples_per_pixel(_samples_per_pixel), bounce_limit(_bounce_limit) {
-        if (srt_create(device, &ctx) != SRT_OK) { std::cerr << "renderer: " << srt_last_error(nullptr) << std::endl; return; }
-        if (srt_upload_scene(ctx, scene) != SRT_OK || srt_set_camera(ctx, &cam) != SRT_OK) std::cerr << "renderer: " << srt_last_error(ctx) << std::endl;
+        if (srt_create(device, &ctx) != SRT_OK) { note(SRT_ERR_NO_DEVICE, srt_last_error(nullptr)); return; }
+        int rc = srt_upload_scene(ctx, scene);
+        if (rc == SRT_OK) rc = srt_set_camera(ctx, &cam);
+        if (rc != SRT_OK) note(rc, srt_last_error(ctx));
     }
-    ~renderer() { if (ctx) srt_destroy(ctx); }
+    renderer(const srt_scene *scene, uint _samples_per_pixel, const srt_camera_data &cam, uint _bounce_limit, const std::vector<int> &devices)
+        : samples_per_pixel(_samples_per_pixel), bounce_limit(_bounce_limit) {
+        int rc = srt_comm_init_all(devices.data(), (int)devices.size(), &comm);
+        if (rc != SRT_OK) { note(rc, srt_comm_last_error(nullptr)); return; }
+        ctx = srt_comm_root_ctx(comm);
+        rc = srt_comm_upload_scene(comm, scene);
+        if (rc == SRT_OK) rc = srt_comm_set_camera(comm, &cam);
+        if (rc != SRT_OK) note(rc, srt_comm_last_error(comm));
+    }
+    ~renderer() { release(); }
     renderer(const renderer &) = delete;
-    renderer &operator=(renderer &&o) noexcept { if (ctx) srt_destroy(ctx); ctx = o.ctx; o.ctx = nullptr; samples_per_pixel = o.samples_per_pixel; bounce_limit = o.bounce_limit;
-                                                 max_chunk_width = o.max_chunk_width; max_chunk_height = o.max_chunk_height; device_inited = o.device_inited; return *this; }
+    renderer &operator=(renderer &&o) noexcept {
+        release();
+        ctx = o.ctx; comm = o.comm; o.ctx = nullptr; o.comm = nullptr;
+        samples_per_pixel = o.samples_per_pixel; bounce_limit = o.bounce_limit;
+        max_chunk_width = o.max_chunk_width; max_chunk_height = o.max_chunk_height; device_inited = o.device_inited;
+        first_error.store(o.first_error.load());
+        return *this;
+    }
     void init_device_params(dim3 _threads, dim3 _blocks, uint _max_chunk_width, uint _max_chunk_height) {   // rendering.cu:279-357
         threads = _threads; blocks = _blocks; max_chunk_width = _max_chunk_width; max_chunk_height = _max_chunk_height;
-        device_inited = ctx && srt_init_device_params(ctx, threads.x, threads.y, blocks.x, blocks.y, max_chunk_width, max_chunk_height, samples_per_pixel,
-                                                      bounce_limit, SRT_DEFAULT_SEED) == SRT_OK;
-        if (!device_inited) std::cerr << "renderer: " << srt_last_error(ctx) << std::endl;
+        int rc = SRT_ERR_INVALID;
+        if (comm) rc = srt_comm_init_device_params(comm, threads.x, threads.y, blocks.x, blocks.y, max_chunk_width, max_chunk_height, samples_per_pixel, bounce_limit, SRT_DEFAULT_SEED);
+        else if (ctx) rc = srt_init_device_params(ctx, threads.x, threads.y, blocks.x, blocks.y, max_chunk_width, max_chunk_height, samples_per_pixel, bounce_limit, SRT_DEFAULT_SEED);
+        device_inited = rc == SRT_OK;
+        if (!device_inited) note(rc, comm ? srt_comm_last_error(comm) : srt_last_error(ctx));
     }
     void render(uint offset_x, uint offset_y) { call_render_kernel(max_chunk_width, max_chunk_height, offset_x, offset_y); }     // rendering.cuh:57-61
     void render(uint width, uint height, uint offset_x, uint offset_y) { call_render_kernel(width, height, offset_x, offset_y); }   // :63-66
@@ -168,19 +190,47 @@ public:
     const float *getDevFBb() const { return plane(2); }
     srt_ctx *getContext() const { return ctx; }
     bool isDeviceInited() const { return device_inited; }
+    // first failing status of any call made through this object (0 = none): the reference exits the process from
+    // checkCudaErrors (utils/cuda_utility.cu:8-18); here the caller decides
+    int getError() const { return first_error.load(); }
+    uint64_t lastRays() const {   // closest-hit queries of the last chunk, all GPUs
+        uint64_t rays = 0;
+        if (comm) { if (srt_comm_stats(comm, &rays, nullptr, nullptr) != SRT_OK) rays = 0; }
+        else if (ctx) { srt_stats st; if (srt_get_stats(ctx, &st) == SRT_OK) rays = st.rays; }
+        return rays;
+    }
 private:
     void call_render_kernel(uint width, uint height, uint offset_x, uint offset_y) {   // rendering.cu:244-277
-        if (!device_inited) { std::cerr << "Device parameters were not initialized, render aborted" << std::endl; return; }
-        if (srt_render_chunk(ctx, width, height, offset_x, offset_y, nullptr) != SRT_OK || srt_scatter_tiles(ctx, nullptr, nullptr) != SRT_OK ||
-            srt_synchronize(ctx) != SRT_OK)
-            std::cerr << "renderer: " << srt_last_error(ctx) << std::endl;
+        if (!device_inited) { std::cerr << "Device parameters were not initialized, render aborted" << std::endl; if (!first_error.load()) first_error.store(SRT_ERR_INVALID); return; }
+        int rc;
+        if (comm) {
+            rc = srt_render_frame_multi(comm, width, height, offset_x, offset_y);
+            if (rc == SRT_OK) rc = srt_comm_synchronize(comm);
+            if (rc != SRT_OK) note(rc, srt_comm_last_error(comm));
+        } else {
+            rc = srt_render_chunk(ctx, width, height, offset_x, offset_y, nullptr);
+            if (rc == SRT_OK) rc = srt_scatter_tiles(ctx, nullptr, nullptr);
+            if (rc == SRT_OK) rc = srt_synchronize(ctx);   // the reference's cudaDeviceSynchronize after the launch (rendering.cu:275-276)
+            if (rc != SRT_OK) note(rc, srt_last_error(ctx));
+        }
+    }
+    void note(int rc, const char *msg) {
+        std::cerr << "renderer: " << (msg ? msg : "error") << std::endl;
+        int expected = 0;
+        first_error.compare_exchange_strong(expected, rc);
+    }
+    void release() {
+        if (comm) { srt_comm_destroy(comm); comm = nullptr; ctx = nullptr; }
+        else if (ctx) { srt_destroy(ctx); ctx = nullptr; }
     }
     const float *plane(int k) const { void *p[3] = {nullptr, nullptr, nullptr}; size_t n = 0; if (ctx) srt_dev_fb(ctx, &p[0], &p[1], &p[2], &n); return (const float *)p[k]; }
-    srt_ctx *ctx = nullptr;
+    srt_ctx *ctx = nullptr;      // single GPU: owned; communicator: rank 0's context (owned by the communicator)
+    srt_comm *comm = nullptr;
     uint samples_per_pixel = 0, bounce_limit = 0;
     uint max_chunk_width = 0, max_chunk_height = 0;
     dim3 blocks, threads;
     bool device_inited = false;
+    std::atomic<int> first_error{0};
 };
 
 // rendering/render_manager.cuh:9-35: one of the two hand-off slots between the render thread and the caller
@@ -211,6 +261,13 @@ public:
         if (scene_inited) { r = renderer(scene, samples_per_pixel, cam->getCameraData(), bounce_limit, device); renderer_inited = true; }
         else std::cerr << "Scene not yet initialized" << std::endl;
     }
+    // the same over several GPUs of one node (tile-interleaved chunks, one RCCL gather per chunk: srt_render_frame_multi)
+    void init_renderer(uint bounce_limit, uint samples_per_pixel, const std::vector<int> &devices) {
+        if (!scene_inited) { std::cerr << "Scene not yet initialized" << std::endl; return; }
+        if (devices.size() <= 1) { init_renderer(bounce_limit, samples_per_pixel, devices.empty() ? 0 : devices[0]); return; }
+        r = renderer(scene, samples_per_pixel, cam->getCameraData(), bounce_limit, devices);
+        renderer_inited = true;
+    }
     void init_device_params(dim3 _threads, dim3 _blocks, uint _chunk_width, uint _chunk_height) {   // render_manager.cu:68-89
         if (!renderer_inited) { std::cerr << "Initialize renderer before assigning device parameters" << std::endl; return; }
         threads = _threads; blocks = _blocks; chunk_width = _chunk_width; chunk_height = _chunk_height;
@@ -238,11 +295,16 @@ public:
         rd->chunk_width = last_chunk_width; rd->chunk_height = last_chunk_height;
         rd->starting_offset_x = offset_x; rd->starting_offset_y = offset_y;
         r.render(last_chunk_width, last_chunk_height, offset_x, offset_y);
-        srt_read_fb(r.getContext(), rd->fb_r.data(), rd->fb_g.data(), rd->fb_b.data());   // the three D2H copies, render_manager.cu:41-45
-        srt_stats st;
-        if (srt_get_stats(r.getContext(), &st) == SRT_OK) total_rays += st.rays;
+        int rc = r.getError();
+        if (rc == SRT_OK) rc = srt_read_fb(r.getContext(), rd->fb_r.data(), rd->fb_g.data(), rd->fb_b.data());   // the three D2H copies, render_manager.cu:41-45
+        if (rc == SRT_OK) total_rays += r.lastRays();
         bool last_step = false;
         i++;
+        if (rc != SRT_OK) {      // a failed chunk ends the render: the consumer sees is_last, the caller reads getError()
+            int expected = 0;
+            first_error.compare_exchange_strong(expected, rc);
+            rd->is_last = true; last_step = true;
+        }
         if (i == n_iterations) { rd->is_last = true; last_step = true; }
         rd->full.release();
         offset_x = (i % x_chunks) * chunk_width;
@@ -271,7 +333,8 @@ public:
         rd->empty.release();
         return !last_read;
     }
-    bool isDone() const { return done; }
+    bool isDone() const { return done.load(); }
+    int getError() const { return first_error.load() ? first_error.load() : r.getError(); }   // 0 = every chunk rendered
     uint64_t getTotalRays() const { return total_rays; }   // closest-hit queries of all chunks rendered so far
     uint getImWidth() const { return image_width; }
     uint getImHeight() const { return image_height; }
@@ -284,7 +347,9 @@ private:
     camera *cam = nullptr;
     frame_buffer *fb = nullptr;
     uint image_width = 0, image_height = 0;
-    bool scene_inited = false, renderer_inited = false, device_inited = false, worker_started = false, done = true;
+    bool scene_inited = false, renderer_inited = false, device_inited = false, worker_started = false;
+    std::atomic<bool> done{true};
+    std::atomic<int> first_error{0};
     renderer r;
     render_step_data render_data_container[2];
     size_t next_write_render_data_index = 0, next_read_render_data_index = 0;

@@ -2,7 +2,7 @@
 // (SURVEY 8(f) rows f2/f3): main.cpp:135-167, io/params.h:236-304, _log_/log_context.cpp:5-65,
 // io/save_image.cpp:8-20 + image/image.cpp:3-18 (CImg replaced by a 30-line BMP writer).
 //
-//   srt_render -s 1 -xr 600 -ar 16/9 -ns 500 -bl 10 -xc 0 -yc 0 -t "my title" --save --do-log [--gpu N] [--sah]
+//   srt_render -s 1 -xr 600 -ar 16/9 -ns 500 -bl 10 -xc 0 -yc 0 -t "my title" --save --do-log [--gpu N | --gpus N] [--sah]
 //
 // Scene ids 0/1/2 are the reference's CORNELL/PRISM/TRIS (io/params.h:15-19); 100/101 are this build's
 // synthetic benchmark scenes.  There is no window (--no-show is accepted and is the only mode).
@@ -35,6 +35,7 @@ struct parameters {   // io/params.h:21-223
     uint xcsize = 0, ycsize = 0, n_samples = 500, bounce_limit = 10;
     bool do_log = false, show_render = true, do_save = false;
     int gpu = 0;
+    int gpus = 1;      // --gpus N: devices 0 .. N-1 of this node render interleaved tiles of every chunk (one RCCL gather per chunk)
     bool sah = false;
 
     void resetYres() { yres = static_cast<uint>(xres / ar); yres = (yres < 1) ? 1 : yres; }   // params.h:176-180
@@ -70,6 +71,7 @@ bool parseArgs(int argc, char **argv, parameters &p) {   // params.h:236-304
             else if (!is_last && (arg == "-ns" || arg == "--nsamples")) p.n_samples = (uint)std::stoul(argv[++i]);
             else if (!is_last && (arg == "-bl" || arg == "--bounce-limit")) p.bounce_limit = (uint)std::stoul(argv[++i]);
             else if (!is_last && arg == "--gpu") p.gpu = std::stoi(argv[++i]);
+            else if (!is_last && arg == "--gpus") p.gpus = std::max(1, std::stoi(argv[++i]));
             else if (arg == "--sah") p.sah = true;
             else if (arg == "--do-log") p.do_log = true;
             else if (arg == "--no-show") p.show_render = false;
@@ -166,7 +168,12 @@ int main(int argc, char **argv) {
     // the scene's own camera builder (scene.cu:259-320), evaluated by the library for this image size
     camera scene_cam = camera::fromData(sm.getCameraData(), pm.ar);
     render_manager rm(sm.getScene(), &scene_cam, &fb);
-    rm.init_renderer(pm.bounce_limit, pm.n_samples, pm.gpu);
+    if (pm.gpus > 1) {
+        std::vector<int> devices;
+        for (int d = 0; d < pm.gpus; d++) devices.push_back(d);
+        rm.init_renderer(pm.bounce_limit, pm.n_samples, devices);
+        lc.add_entry("gpus", pm.gpus);
+    } else rm.init_renderer(pm.bounce_limit, pm.n_samples, pm.gpu);
     lc.add_entry("samples per pixel", pm.n_samples);                        // render_manager.cu:124-126
     lc.add_entry("bounce limit", pm.bounce_limit);
     rm.init_device_params(pm.getXcsize(), pm.getYcsize());
@@ -192,9 +199,11 @@ int main(int argc, char **argv) {
     lc.add_entry("Mpath/s", (double)pm.xres * pm.yres * pm.n_samples / seconds / 1e6);
     std::clog << (double)rays / seconds / 1e6 << " Mray/s" << std::endl;
 
+    if (rm.getError() != SRT_OK) lc.add_entry("render error", rm.getError());
     if (pm.do_log) lc.to_file();
     std::string image_filename = pm.getImgTitle() + ".bmp";
     string_to_filename(image_filename);
     if (pm.do_save) save_img(ch, pm.xres, pm.yres, image_filename);
+    if (rm.getError() != SRT_OK) { std::cerr << "render failed with status " << rm.getError() << " (the image is incomplete)" << std::endl; return 3; }
     return 0;
 }

@@ -35,5 +35,5 @@ int main(int argc, char **argv) {
     std::fwrite(fb.b, sizeof(float), fb.channel_size, f);
     std::fclose(f);
     std::printf("done %zu pixels, first uchar %d\n", fb.channel_size, (int)chn.r[0]);
-    return rm.isDone() ? 0 : 1;
+    return (rm.isDone() && rm.getError() == SRT_OK) ? 0 : 1;
 }

@@ -354,6 +354,27 @@ def test_full_resolution_mesh100k_blocks_bit_exact(srt, gpu, orc):
     assert _blocks_bit_exact(srt, gpu, orc, srt.SCENE_MESH100K, srt.BVH_SAH, 3840, 2160, 64, 16, 2000, 4100, 6) >= 4
 
 
+def test_cfg1_cornell_exact_size_full_image(srt, gpu, orc):
+    """BASELINE cfg 1 at its exact size: the reference's CORNELL scene (own coloured-wall spectra, see DESIGN D-colours),
+    256x256, 16 spp, depth 8, reference BVH builder; the WHOLE image against the oracle, bit for bit."""
+    import os
+    scene = srt.Scene.builtin(srt.SCENE_CORNELL, 0).build_bvh(srt.BVH_REFERENCE, 1984)
+    W = H = 256
+    cam = scene.default_camera(W, H)
+    out = srt.render_image(scene, cam, W, H, 16, 8, renderer=gpu)
+    ref = oracle_scene_for(orc, scene, 0).render(cam, W, H, 16, 8, threads=min(os.cpu_count() or 1, 16))
+    assert_planes_equal(out["xyz"], ref["xyz"], "XYZ sums")
+    assert_planes_equal(out["lin"], ref["lin"], "unquantised sRGB")
+    assert_planes_equal(out["fb"], ref["fb"], "quantised framebuffer")
+    assert out["stats"]["rays"] == ref["stats"]["rays"] and out["stats"]["paths"] == W * H * 16
+
+
+def test_cfg2_exact_size_blocks_bit_exact(srt, gpu, orc):
+    """BASELINE cfg 2 at its exact size: random-spheres scene, 1280x720, 256 spp, depth 16 (SAH tree); a handful of the
+    reference's 28x16 blocks spread over the image against the oracle at full spp, bit for bit."""
+    assert _blocks_bit_exact(srt, gpu, orc, srt.SCENE_RANDOM_SPHERES, srt.BVH_SAH, 1280, 720, 256, 16, 97, 263, 9) >= 6
+
+
 def test_invalid_calls_fail_without_side_effects(srt, gpu):
     """Error behaviour of the boundary: bad arguments come back as negative codes with a message, nothing exits or faults
     (the reference calls exit(99) from checkCudaErrors, utils/cuda_utility.cu:8-18)."""

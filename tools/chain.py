@@ -13,7 +13,7 @@ r.upload_scene(scene); r.set_camera(cam); r.set_partition(0, 1)
 r.init_device_params(W, H, 32, depth, 1984)
 r.render_chunk(W, H); r.synchronize()
 cost = r.tile_costs().astype(np.float64)
-tiles_x = (W + 7) // 8
+tiles_x = (28 * (W // 28 + 1) + 7) // 8      # tiles cover the whole reference grid (srt_render_chunk)
 order = np.argsort(-cost)
 print("tiles", cost.size, "mean", cost.mean(), "max/mean", cost.max() / cost.mean(), "top10/mean", (cost[order[:10]] / cost.mean()).round(1).tolist())
 for q in (50, 90, 99, 99.9):

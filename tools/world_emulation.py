@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Strong-scaling emulation on ONE GPU: renders every rank's share of a W-rank job, one after the other, and reports the
+render-kernel time of each rank and the max over ranks (= what the W-GPU frame would take, gather aside)."""
+import argparse, importlib, json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+srt = importlib.import_module("cuda-spectral-ray-tracer_amd")
+ap = argparse.ArgumentParser()
+ap.add_argument("--scene", type=int, default=100); ap.add_argument("--bvh", type=int, default=1)
+ap.add_argument("--width", type=int, default=1920); ap.add_argument("--height", type=int, default=1080)
+ap.add_argument("--spp", type=int, default=1024); ap.add_argument("--depth", type=int, default=16)
+ap.add_argument("--worlds", default="1,2,4,8"); ap.add_argument("--reps", type=int, default=1)
+a = ap.parse_args()
+scene = srt.Scene.builtin(a.scene, 0).build_bvh(a.bvh, 1984)
+cam = scene.default_camera(a.width, a.height)
+r = srt.Renderer(0)
+r.upload_scene(scene); r.set_camera(cam)
+out = {}
+for W in [int(x) for x in a.worlds.split(",")]:
+    ms = []
+    for rank in range(W):
+        r.set_partition(rank, W)
+        best = 1e30
+        for _ in range(a.reps):
+            r.init_device_params(a.width, a.height, a.spp, a.depth, 1984)
+            r.render_chunk(a.width, a.height); r.synchronize()
+            best = min(best, r.last_kernel_ms())
+        ms.append(round(best, 1))
+    out[W] = {"per_rank_ms": ms, "max_ms": max(ms), "speedup_vs_1": None}
+    print("world %d: max %.1f ms, ranks %s" % (W, max(ms), ms), flush=True)
+base = out.get(1, {}).get("max_ms")
+for W in out:
+    out[W]["speedup_vs_1"] = (base / out[W]["max_ms"]) if base else None
+print(json.dumps(out))
