@@ -41,7 +41,10 @@ struct srt_ctx {
     uint32_t waves_per_cu = 0;                         // experiment knob (env SRT_WAVES_PER_CU)
     // step choice of a wave: serve the kind of work (shade / fringe / inner) with the most waiting lanes per unit of cost;
     // weights = 256 / relative cost of the step (inner = 256).
-    uint32_t score_shade = 70, score_fringe = 280;      // env SRT_SCORE_SHADE / SRT_SCORE_FRINGE
+    // Defaults: 70 / 280 when the whole inner tree is LDS resident, 140 / 560 when inner records beyond the cache come from
+    // L2 (an inner step then costs about twice as much, so the other two kinds weigh twice as much relative to it);
+    // measured plateaus: profiles/r02/knob_sweeps.txt.  0 = not set by the environment.
+    uint32_t score_shade = 0, score_fringe = 0;        // env SRT_SCORE_SHADE / SRT_SCORE_FRINGE
     uint32_t debug_lane_limit = 0;                     // env SRT_DEBUG_LANE_LIMIT (experiments: partial tiles)
     uint32_t split_load_pct = 145;                    // env SRT_SPLIT_LOAD: load factor (%) of the capacity constraint in order_tiles_kernel's split policy (0 = never split)
     uint32_t probe_spp = 2;                            // samples of the cost probe (env SRT_PROBE_SPP, 0 = no ordering)
@@ -248,7 +251,13 @@ int srt_render_chunk(srt_ctx *c, uint32_t width, uint32_t height, uint32_t offx,
     p.tiles_local = c->tiles_local;
     p.pixel_counter = (uint32_t *)(c->d_counters + kCounters);
     p.waves_per_cu_override = c->waves_per_cu;
-    p.score_shade = c->score_shade; p.score_fringe = c->score_fringe;
+    {
+        int wpb = 1, n_cached = 0;
+        render_launch_shape(c->stack_depth, c->n_records, c->n_inner, wpb, n_cached);
+        const bool all_cached = n_cached == c->n_inner;
+        p.score_shade = c->score_shade ? c->score_shade : (all_cached ? 70u : 140u);
+        p.score_fringe = c->score_fringe ? c->score_fringe : (all_cached ? 280u : 560u);
+    }
     // ---- cost-ordered pixel queue --------------------------------------------------------------------------------
     // A pixel is one sequential RNG stream, so the launch cannot finish before its most expensive pixel does.  A short
     // probe (probe_spp samples per pixel from a copy of the RNG state, nothing written) measures the traversal cost of
