@@ -46,7 +46,7 @@ struct srt_ctx {
     // measured plateaus: profiles/r02/knob_sweeps.txt.  0 = not set by the environment.
     uint32_t score_shade = 0, score_fringe = 0;        // env SRT_SCORE_SHADE / SRT_SCORE_FRINGE
     uint32_t debug_lane_limit = 0;                     // env SRT_DEBUG_LANE_LIMIT (experiments: partial tiles)
-    uint32_t split_load_pct = 145;                    // env SRT_SPLIT_LOAD: load factor (%) of the capacity constraint in order_tiles_kernel's split policy (0 = never split)
+    uint32_t split_load_pct = 200;                    // env SRT_SPLIT_LOAD: load factor (%) of the capacity constraint in order_tiles_kernel's split policy (0 = never split)
     uint32_t probe_spp = 2;                            // samples of the cost probe (env SRT_PROBE_SPP, 0 = no ordering)
     uint32_t *d_tile_cost = nullptr, *d_tile_order = nullptr;
     size_t tile_sched_capacity = 0;

@@ -597,7 +597,10 @@ __global__ __launch_bounds__(1024) void order_tiles_kernel(const uint32_t *__res
     __syncthreads();
 
     // latency of a tile relative to the same tile at 64 pixels per wave, by split level (pixels per wave 64 .. 1)
-    const float g[7] = {1.0f, 0.957f, 0.863f, 0.794f, 0.767f, 0.687f, 0.442f};
+    // (measured on the most expensive tile of cfg 3 with the v15 kernel, alone on the GPU: 164 / 153 / 152 / 131 / 123 / 108 / 80 ms for
+    // 64 / 32 / 16 / 8 / 4 / 2 / 1 pixels per wave, tools/lone_tile.py; the ratios are a property of the kernel's lane sharing, not of
+    // the scene: the policy only needs their order of magnitude)
+    const float g[7] = {1.0f, 0.934f, 0.925f, 0.797f, 0.747f, 0.656f, 0.485f};
     auto level_for = [&](uint32_t c, float target) {
         uint32_t s = 0;
         while (s < 6u && (float)c * g[s] > target) s++;

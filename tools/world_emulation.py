@@ -15,6 +15,7 @@ scene = srt.Scene.builtin(a.scene, 0).build_bvh(a.bvh, 1984)
 cam = scene.default_camera(a.width, a.height)
 r = srt.Renderer(0)
 r.upload_scene(scene); r.set_camera(cam)
+r.set_partition(0, 1); r.init_device_params(a.width, a.height, 8, a.depth, 1984); r.render_chunk(a.width, a.height); r.synchronize()   # warm-up
 out = {}
 for W in [int(x) for x in a.worlds.split(",")]:
     ms = []
