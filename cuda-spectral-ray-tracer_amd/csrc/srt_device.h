@@ -1,10 +1,13 @@
 // srt_device.h -- gfx950 device arithmetic of the spectral path tracer.
 //
 // Every function restates one piece of the reference's device library (file:line cited) with the
-// reference's IEEE-754 fp32 operation order.  This translation unit is compiled with
-// -ffp-contract=off and correctly rounded fp32 divide/sqrt, no fast-math: the parity tests require
-// bit-identical results to the CPU oracle, because the estimator's discrete decisions (hit/miss at
-// an edge, reflect/refract, rejection accept) flip on 1-ulp differences (DESIGN.md "Exactness").
+// operation order of the reference's SOURCE under plain IEEE-754 fp32 semantics: this translation unit
+// is compiled with -ffp-contract=off and correctly rounded fp32 divide/sqrt, no fast-math, and the parity
+// tests require bit-identical results to the CPU oracle (oracle/), because the estimator's discrete
+// decisions (hit/miss at an edge, reflect/refract, rejection accept) flip on 1-ulp differences.
+// "Exact" therefore means: equal to the no-FMA reading of the source that the oracle embodies.  The real
+// nvcc build contracts a*b+c into FMAs by default and has its own powf; equivalence to THAT binary is
+// statistical only and cannot be pinned here (DESIGN.md sections 2 and 3).
 //
 // Data layout is this build's own (DESIGN.md "HBM layout"): paired-child 64-byte BVH records,
 // 48-byte triangle records with the 2-D projected vertices, spectra as (s[k], s[k+1]) pairs.
