@@ -3,9 +3,9 @@
 // Every function restates one piece of the reference's device library (file:line cited) with the
 // operation order of the reference's SOURCE under plain IEEE-754 fp32 semantics: this translation unit
 // is compiled with -ffp-contract=off and correctly rounded fp32 divide/sqrt, no fast-math, and the parity
-// tests require bit-identical results to the CPU oracle (oracle/), because the estimator's discrete
+// tests require bit-identical results to the CPU oracle, because the estimator's discrete
 // decisions (hit/miss at an edge, reflect/refract, rejection accept) flip on 1-ulp differences.
-// "Exact" therefore means: equal to the no-FMA reading of the source that the oracle embodies.  The real
+// "Exact" therefore means: equal to the no-FMA reading of the source that the CPU oracle embodies.  The real
 // nvcc build contracts a*b+c into FMAs by default and has its own powf; equivalence to THAT binary is
 // statistical only and cannot be pinned here (DESIGN.md sections 2 and 3).
 //

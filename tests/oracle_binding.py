@@ -5,7 +5,7 @@ import os
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ORACLE_SO = os.path.join(ROOT, "oracle", "_build", "libsrt_oracle.so")
+ORACLE_SO = os.environ.get("SRT_ORACLE_SO") or os.path.join(ROOT, "oracle", "_build", "libsrt_oracle.so")   # (override: sanitizer build)
 
 
 class Rng(C.Structure):
