@@ -434,15 +434,22 @@ __device__ __forceinline__ void trav_step_inner(Trav &tv, const NodeSrc &ns, V3 
     trav_advance(tv, trav_l, trav_r, lref, rref, below);
 }
 
-// Visit of a FRINGE record (at least one leaf child).
-template <bool COUNT, bool NARROW>
-__device__ __forceinline__ void trav_step_fringe(Trav &tv, const NodeSrc &ns, V3 o, V3 d,
-                                                 V3 inv, const StackRef &stack, TravStats &ts) {
+// Visit of a FRINGE record (at least one leaf child), in two halves so that a caller can put independent work (a burst of
+// INNER steps for other lanes of the wave) between the loads and their first use: the record comes from L2, several hundred
+// cycles away.
+struct FringeFetch { f4v q0, q1, q2, q3, q4, q5; int below; };
+template <bool NARROW>
+__device__ __forceinline__ void trav_fringe_fetch(FringeFetch &ff, const Trav &tv, const NodeSrc &ns, const StackRef &stack) {
     // one round of independent loads: 12 (left, right) pairs = six 16-byte loads (record layout: flatten_scene)
     const uint32_t off = __umul24((uint32_t)(tv.node - ns.n_inner), 96u);   // (full-rate 24-bit multiply; < 2^24 fringe records)
-    const f4v q0 = buf_load16(ns.global_fringe, off), q1 = buf_load16(ns.global_fringe, off + 16u), q2 = buf_load16(ns.global_fringe, off + 32u);
-    const f4v q3 = buf_load16(ns.global_fringe, off + 48u), q4 = buf_load16(ns.global_fringe, off + 64u), q5 = buf_load16(ns.global_fringe, off + 80u);
-    const int below = stack_exchange<NARROW>(stack, tv.sp, tv.top);
+    ff.q0 = buf_load16(ns.global_fringe, off); ff.q1 = buf_load16(ns.global_fringe, off + 16u); ff.q2 = buf_load16(ns.global_fringe, off + 32u);
+    ff.q3 = buf_load16(ns.global_fringe, off + 48u); ff.q4 = buf_load16(ns.global_fringe, off + 64u); ff.q5 = buf_load16(ns.global_fringe, off + 80u);
+    ff.below = stack_exchange<NARROW>(stack, tv.sp, tv.top);
+}
+template <bool COUNT>
+__device__ __forceinline__ void trav_fringe_compute(const FringeFetch &ff, Trav &tv, V3 o, V3 d, V3 inv, TravStats &ts) {
+    const f4v q0 = ff.q0, q1 = ff.q1, q2 = ff.q2, q3 = ff.q3, q4 = ff.q4, q5 = ff.q5;
+    const int below = ff.below;
     const f2 w0 = mk2(q0.x, q0.y), w1 = mk2(q0.z, q0.w), w2 = mk2(q1.x, q1.y), w3 = mk2(q1.z, q1.w), w4 = mk2(q2.x, q2.y), w5 = mk2(q2.z, q2.w);
     const f2 w6 = mk2(q3.x, q3.y), w7 = mk2(q3.z, q3.w), w8 = mk2(q4.x, q4.y), w9 = mk2(q4.z, q4.w);
     const uint32_t fl = __float_as_uint(q5.x), fr = __float_as_uint(q5.y);
@@ -498,6 +505,12 @@ __device__ __forceinline__ void trav_step_fringe(Trav &tv, const NodeSrc &ns, V3
     tv.c = c2;
     tv.hit = hit_r ? ~rref : (hit_l ? ~lref : tv.hit);
     trav_advance(tv, trav_l, trav_r, lref, rref, below);
+}
+template <bool COUNT, bool NARROW>
+__device__ __forceinline__ void trav_step_fringe(Trav &tv, const NodeSrc &ns, V3 o, V3 d, V3 inv, const StackRef &stack, TravStats &ts) {
+    FringeFetch ff;
+    trav_fringe_fetch<NARROW>(ff, tv, ns, stack);
+    trav_fringe_compute<COUNT>(ff, tv, o, d, inv, ts);
 }
 
 }  // namespace srt
