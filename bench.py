@@ -320,7 +320,7 @@ def main():
             "config": {"workload": "%s (%d tris, %d BVH nodes), %dx%d, %d spp, depth %d" %
                                    (SCENE_NAMES.get(args.scene, "scene %d" % args.scene), scene.n_tris, scene.n_nodes, W, H, args.spp, args.depth),
                        "scene_id": args.scene,
-                       "bvh": "SAH-128, one triangle per leaf, children ordered by distance to the scene's default camera" if args.bvh == 1 else "reference builder (bvh/bvh.cu:206-346)",
+                       "bvh": "SAH (exact sweep below 8192 triangles, 256 bins above), one triangle per leaf, children ordered by distance to the scene's default camera" if args.bvh == 1 else "reference builder (bvh/bvh.cu:206-346)",
                        "nan_direction_rays": "%.2f %% of the counted rays have a NaN direction (Sellmeier quirk Q1) and are answered 'miss' without walking the tree" % (100.0 * nan_c / rays_c),
                        "tiles": "8x8 px per wave, rank = tile % n_gpus", "gather": gather_via},
             "mpath_per_s": (W * H * args.spp * steps) / elapsed / 1e6,
