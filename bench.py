@@ -135,6 +135,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-calibration", action="store_true", help="skip the issue-rate microkernel and the copy-rate measurement (profiling passes)")
     ap.add_argument("--torch-gather", action="store_true", help="N > 1: gather through torch.distributed instead of the library's RCCL communicator")
+    ap.add_argument("--rehearse-gloo", action="store_true",
+                    help="rehearsal of the N > 1 control flow on ONE GPU: every rank uses cuda:0, torch.distributed runs on gloo and the gather goes through host memory (never used for reported numbers)")
     args = ap.parse_args()
 
     import torch
@@ -149,12 +151,16 @@ def main():
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
-    if local_rank >= torch.cuda.device_count():      # launcher restricted each rank's visible devices to its own GPU
+    if args.rehearse_gloo or local_rank >= torch.cuda.device_count():      # (launcher restricted each rank's visible devices to its own GPU)
         local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.rehearse_gloo:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    red_dev = "cpu" if args.rehearse_gloo else "cuda"       # where the small statistics tensors of the reductions live
 
     import __graft_entry__
     srt = __graft_entry__._pkg()
@@ -177,16 +183,22 @@ def main():
     comm, gather_via = None, "none (1 GPU)"
     if world > 1:
         gather_via = "torch.distributed gather"
-        if not args.torch_gather:
-            try:
-                ident = [srt.Comm.unique_id() if rank == 0 else None]
-                dist.broadcast_object_list(ident, src=0)
-                comm = srt.Comm.init_rank(r, ident[0], rank, world)
-                gather_via = "srt_render_frame_multi (ncclGather inside libsrt_hip.so)"
-            except Exception as e:      # noqa: BLE001 -- any failure here must not lose the measurement
-                log("rank %d: library communicator unavailable (%r); using torch.distributed for the gather" % (rank, e))
-                comm = None
-            ok = torch.tensor([1.0 if comm is not None else 0.0], device="cuda")
+        if not args.torch_gather and not args.rehearse_gloo:
+            ident = [None]
+            if rank == 0:
+                try:
+                    ident[0] = srt.Comm.unique_id()
+                except Exception as e:      # noqa: BLE001 -- any failure here must not lose the measurement
+                    log("library communicator unavailable (%r); using torch.distributed for the gather" % (e,))
+            dist.broadcast_object_list(ident, src=0)      # every rank takes part, whatever rank 0 got
+            if ident[0] is not None:
+                try:
+                    comm = srt.Comm.init_rank(r, ident[0], rank, world)
+                    gather_via = "srt_render_frame_multi (ncclGather inside libsrt_hip.so)"
+                except Exception as e:      # noqa: BLE001
+                    log("rank %d: srt_comm_init_rank failed (%r); using torch.distributed for the gather" % (rank, e))
+                    comm = None
+            ok = torch.tensor([1.0 if comm is not None else 0.0], device=red_dev)
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             if float(ok[0]) < 0.5 and comm is not None:      # every rank or none
                 comm.close()
@@ -199,7 +211,7 @@ def main():
     r.set_count_traversal(True)
     r.render_chunk(W, H, 0, 0, stream)
     st = r.stats()
-    cnt = torch.tensor([st["rays"], st["node_visits"], st["tri_tests"], st["paths"], st["util"][2]], dtype=torch.float64, device="cuda")
+    cnt = torch.tensor([st["rays"], st["node_visits"], st["tri_tests"], st["paths"], st["util"][2]], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(cnt)
     rays_c, V_c, T_c, paths_c, nan_c = [float(x) for x in cnt.tolist()]
@@ -236,9 +248,16 @@ def main():
                 _, _, _, tp = r.tile_buffer()
                 local_tiles = torch.empty((tp, tiles.PLANES, tiles.LANES), dtype=torch.float32, device="cuda")
             r.copy_tile_buffer(local_tiles.data_ptr(), stream)        # stream-ordered D2D into the tensor RCCL sends
-            g = tiles.gather_tiles(local_tiles, rank, world)          # the single collective of the path
+            if args.rehearse_gloo:
+                torch.cuda.current_stream().synchronize()
+                gh = tiles.gather_tiles(local_tiles.cpu(), rank, world)
+                g = gh.cuda() if rank == 0 else None
+            else:
+                g = tiles.gather_tiles(local_tiles, rank, world)      # the single collective of the path
             if rank == 0:
                 r.scatter_tiles(g.data_ptr(), stream)
+                if args.rehearse_gloo:
+                    torch.cuda.current_stream().synchronize()          # g is a temporary
 
     def barrier():
         if world > 1:
@@ -267,7 +286,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
 
-    tot = torch.tensor([float(rays_local), elapsed, sum(kernel_ms) / max(len(kernel_ms), 1)], dtype=torch.float64, device="cuda")
+    tot = torch.tensor([float(rays_local), elapsed, sum(kernel_ms) / max(len(kernel_ms), 1)], dtype=torch.float64, device=red_dev)
     if world > 1:
         rays_t = tot[0:1].clone(); dist.all_reduce(rays_t)
         mx = tot[1:3].clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)

@@ -11,6 +11,9 @@
 // fetched with four coalesced-per-lane 16-byte loads, and the hit record is just (t, triangle).
 //
 // Build: hipcc --offload-arch=gfx950 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt
+#include <algorithm>
+#include <stdlib.h>
+
 #include "srt_device.h"
 #include "srt_internal.h"
 
@@ -66,6 +69,7 @@ void render_launch_shape(int stack_depth, int n_records, int n_inner, int &waves
     const size_t fixed = (size_t)kLdsTablesF4 * 16 + waves_per_block * stack + 64;
     size_t room = per_block > fixed ? (per_block - fixed) / (narrow_refs(n_records) ? 52 : 56) : 0;
     if (room > (size_t)n_inner) room = (size_t)n_inner;
+    if (const char *ev = getenv("SRT_LDS_CACHE_MAX")) room = std::min(room, (size_t)std::max(0, atoi(ev)));   // experiment knob
     n_cached = (int)room;
 }
 

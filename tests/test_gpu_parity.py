@@ -198,6 +198,8 @@ def test_ragged_chunks_multi_rank_match_oracle(srt, orc):
         s = orc.Rng()
         orc.lib().orc_rng_init(1984 + idx, C.byref(s))
         states[6 * idx: 6 * idx + 6] = [s.d] + list(s.v)
+    image = tuple(np.full(W * H, -1.0, np.float32) for _ in range(3))      # row-major planes filled chunk by chunk (update_fb)
+    want_image = [np.full(W * H, -1.0, np.float32) for _ in range(3)]
     for oy in range(0, H, ch):
         for ox in range(0, W, cw):
             w, h = min(cw, W - ox), min(ch, H - oy)
@@ -223,6 +225,15 @@ def test_ragged_chunks_multi_rank_match_oracle(srt, orc):
             for c in range(3):
                 assert np.array_equal(bits(got_xyz[c][inside]), bits(want["xyz"][c][inside])), ("chunk", ox, oy, "xyz", c)
                 assert np.array_equal(got_fb[c][inside], want["fb"][c][inside]), ("chunk", ox, oy, "fb", c)
+            # srt_read_fb_rowmajor writes exactly the chunk's rectangle of the caller's planes (render_manager::update_fb)
+            ranks[0].read_fb_rowmajor(W, H, into=image)
+            for c in range(3):
+                img = orc.unswizzle(want["fb"][c], 28, 16, bx, by, w, h, ox, oy, W, H)
+                mask = np.zeros((H, W), bool)
+                mask[oy:oy + h, ox:ox + w] = True
+                want_image[c][mask.ravel()] = img[mask.ravel()]
+                assert np.array_equal(image[c], want_image[c]), ("row-major after chunk", ox, oy, c)
+    assert all(float(p.min()) >= 0.0 for p in image)            # every pixel of the image was written by some chunk
     for r in ranks:
         r.close()
 
