@@ -95,3 +95,15 @@ def test_cli_driver_writes_bmp_and_log(srt, orc, tmp_path):
     for c, plane in enumerate(ref["fb"]):
         want = orc.unswizzle(plane, 28, 16, W // 28 + 1, H // 16 + 1, W, H, 0, 0, W, H).reshape(H, W).astype(np.uint8)
         assert np.array_equal(img[:, :, 2 - c], want)
+
+
+@pytest.mark.gpu
+def test_cli_driver_reports_failure(srt, tmp_path):
+    """A render that cannot run (device index that does not exist; more GPUs than the box has) must not exit 0 with a black
+    image: the reference dies in checkCudaErrors -> exit(99) (utils/cuda_utility.cu:8-18), this driver returns non-zero."""
+    exe = os.path.join(PKG, "srt_render")
+    for extra in (["--gpu", "63"], ["--gpus", "64"]):
+        p = subprocess.run([exe, "-s", "1", "-xr", "32", "-ar", "4/3", "-ns", "2", "-bl", "4", "-t", "fail", "--no-show"] + extra,
+                           cwd=str(tmp_path), capture_output=True, timeout=120)
+        assert p.returncode != 0, extra
+        assert b"renderer:" in p.stderr or b"not yet initialized" in p.stderr, p.stderr[-300:]
