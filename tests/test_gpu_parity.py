@@ -454,3 +454,60 @@ def test_comm_two_gpus_bit_identical(srt, gpu, orc):
     assert_planes_equal(fb, ref["fb"], "2 GPUs fb"); assert_planes_equal(xyz, ref["xyz"], "2 GPUs xyz")
     assert st["rays"] == ref["stats"]["rays"]
     comm.close()
+
+
+def _custom_scene(srt, tris, mats, bg_rgb=(0.5, 0.5, 0.5)):
+    """Scene from raw arrays (the boundary's srt_scene_set_* path): tris = [(v0, v1, v2, mat, aa_plane)], mats = [(type, rgb, fuzz, power)]."""
+    import ctypes as C
+    B = srt.binding
+    T = (B.TriIn * len(tris))()
+    for k, (v0, v1, v2, mat, aap) in enumerate(tris):
+        T[k].v0[:] = v0; T[k].v1[:] = v1; T[k].v2[:] = v2; T[k].mat_index = mat; T[k].aa_plane = aap
+    M = (B.Material * len(mats))()
+    for k, (mtype, rgb, fuzz, power) in enumerate(mats):
+        M[k].col[:] = rgb; M[k].reflection_fuzz = fuzz; M[k].material_type = mtype; M[k].emission_power = power
+        M[k].sellmeier_B[:] = (1.03961212, 0.231792344, 1.01046945); M[k].sellmeier_C[:] = (1.03961212, 0.231792344, 1.01046945)   # Q1: C := B
+        B.check(B.lib().srt_material_bake(C.byref(M[k])))
+    bg = np.zeros(B.N_CIE, np.float32)
+    B.check(B.lib().srt_background_spectrum((C.c_float * 3)(*bg_rgb), B.fptr(bg)))
+    return srt.Scene.from_arrays(T, M, bg)
+
+
+@pytest.mark.parametrize("case", ["one_triangle", "two_triangles", "degenerate_and_odd_materials", "forty_materials"])
+def test_custom_scenes_edge_cases(srt, gpu, orc, case):
+    """Scenes that come in through srt_scene_set_* (not the built-ins): a BVH whose root is a leaf (bvh.cu:114-119), a two-leaf
+    tree (one FRINGE record, no INNER record), zero-area / needle triangles (NaN normal: every test on them fails, as in the
+    reference), material types the switch sends to its default branch (NO_MAT = 6, an unknown id), an emissive surface, and more
+    than 32 materials (the reference would read its 32-entry shared copy out of bounds, Q16; the build indexes the real table)."""
+    XY, NONE = 1, 0
+    wall = lambda z, m: [((-4, -4, z), (4, -4, z), (4, 4, z), m, NONE), ((-4, -4, z), (4, 4, z), (-4, 4, z), m, NONE)]
+    if case == "one_triangle":
+        tris = [((-3, -2, 0), (3, -2, 0), (0, 3, 0), 0, NONE)]
+        mats = [(srt.binding.MAT_LAMBERTIAN, (0.5, 0.5, 0.5), 0.0, 0.0)]
+    elif case == "two_triangles":
+        tris = wall(0.0, 0)
+        mats = [(srt.binding.MAT_METALLIC, (1.0, 1.0, 1.0), 0.3, 0.0)]
+    elif case == "degenerate_and_odd_materials":
+        tris = wall(0.0, 0) + wall(-1.5, 1) + [((0, 0, 1), (0, 0, 1), (0, 0, 1), 2, NONE),          # a point
+                                               ((-1, 0, 2), (0, 0, 2), (1, 0, 2), 3, NONE),          # a needle (collinear vertices)
+                                               ((-2, -2, 3), (2, -2, 3), (0, 2, 3), 4, XY)]
+        mats = [(srt.binding.MAT_NO_MAT, (1.0, 1.0, 1.0), 0.0, 0.0), (srt.binding.MAT_EMISSIVE, (1.0, 1.0, 1.0), 0.0, 3.0),
+                (srt.binding.MAT_DIELECTRIC, (1.0, 1.0, 1.0), 0.0, 0.0), (17, (0.5, 0.5, 0.5), 0.0, 0.0),
+                (srt.binding.MAT_DIELECTRIC, (1.0, 1.0, 1.0), 0.0, 0.0)]
+    else:
+        tris, mats = [], []
+        for k in range(40):
+            x = -3.9 + 0.2 * k
+            tris.append(((x, -3, 0.1 * k), (x + 0.19, -3, 0.1 * k), (x + 0.1, 3, 0.1 * k), k, NONE))
+            mats.append(((srt.binding.MAT_LAMBERTIAN, srt.binding.MAT_METALLIC, srt.binding.MAT_DIELECTRIC)[k % 3], (0.5, 0.5, 0.5) if k % 2 else (1.0, 1.0, 1.0), 0.1 * (k % 4), 0.0))
+    scene = _custom_scene(srt, tris, mats).build_bvh(srt.BVH_REFERENCE, 1984)
+    W, H, spp, depth = 45, 37, 6, 6
+    cam = srt.camera_init(W, H, 60.0, (0.3, 0.2, 9.0), (0.0, 0.0, 0.0))
+    out = srt.render_image(scene, cam, W, H, spp, depth, renderer=gpu, count_traversal=True)
+    osc = oracle_scene_for(orc, scene, 0)
+    ref = osc.render(cam, W, H, spp, depth)
+    assert_planes_equal(out["xyz"], ref["xyz"], case + " XYZ")
+    assert_planes_equal(out["fb"], ref["fb"], case + " fb")
+    assert out["stats"]["rays"] == ref["stats"]["rays"]
+    if case != "degenerate_and_odd_materials":
+        assert max(float(p.max()) for p in out["xyz"]) > 0       # the camera sees something
