@@ -511,3 +511,46 @@ def test_custom_scenes_edge_cases(srt, gpu, orc, case):
     assert out["stats"]["rays"] == ref["stats"]["rays"]
     if case != "degenerate_and_odd_materials":
         assert max(float(p.max()) for p in out["xyz"]) > 0       # the camera sees something
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_scenes_fuzz(srt, gpu, orc, seed):
+    """Random triangle soups with random materials, cameras and builders (both BVH builders, lens on / off, thin and
+    axis-aligned triangles, shared edges and vertices so that exact t ties occur -- Q11): GPU == oracle bit for bit,
+    work counters included."""
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.integers(3, 260))
+    tris, mats = [], []
+    n_mats = int(rng.integers(1, 12))
+    for k in range(n_mats):
+        mtype = int(rng.choice([0, 0, 0, 1, 1, 2, 4, 6]))
+        grey = float(rng.choice([0.0, 0.3, 0.5, 0.73, 1.0]))
+        mats.append((mtype, (grey, grey, grey), float(rng.uniform(0, 0.6)), float(rng.uniform(0.5, 3.0))))
+    verts = rng.uniform(-5, 5, (max(4, n // 2), 3)).astype(np.float32)
+    lattice = rng.random(verts.shape[0]) < 0.3
+    verts[lattice] = np.round(verts[lattice])          # some vertices on lattice points: coplanar / axis-aligned coincidences
+    for k in range(n):
+        if rng.random() < 0.6:          # triangles that share vertices (a mesh-like soup: shared edges)
+            i0, i1, i2 = rng.choice(verts.shape[0], 3, replace=False)
+            v0, v1, v2 = verts[i0], verts[i1], verts[i2]
+        else:
+            c = rng.uniform(-5, 5, 3)
+            v0, v1, v2 = (c + rng.normal(0, rng.choice([0.01, 0.5, 2.0]), 3) for _ in range(3))
+        if rng.random() < 0.15:         # axis-aligned: exercises the aa_plane projection choice (tri.cu:66-77)
+            ax = int(rng.integers(0, 3)); v0 = np.array(v0); v1 = np.array(v1); v2 = np.array(v2)
+            v1[ax] = v0[ax]; v2[ax] = v0[ax]
+        tris.append((tuple(float(x) for x in v0), tuple(float(x) for x in v1), tuple(float(x) for x in v2), int(rng.integers(0, n_mats)), int(rng.choice([0, 0, 1, 2, 3]))))
+    bg = float(rng.choice([0.5, 1.0, 0.5, 0.0]))
+    mode = int(rng.integers(0, 2))
+    scene = _custom_scene(srt, tris, mats, (bg, bg, bg)).build_bvh(mode, 1984)
+    W, H, spp, depth = int(rng.integers(9, 70)), int(rng.integers(9, 50)), int(rng.integers(1, 7)), int(rng.integers(1, 17))
+    cam = srt.camera_init(W, H, float(rng.uniform(20, 90)), tuple(rng.uniform(-12, 12, 3)), tuple(rng.uniform(-2, 2, 3)),
+                          defocus_angle=float(rng.choice([0.0, 0.0, 1.5])), focus_dist=float(rng.uniform(5, 15)))
+    out = srt.render_image(scene, cam, W, H, spp, depth, renderer=gpu, count_traversal=True)
+    ref = oracle_scene_for(orc, scene, mode).render(cam, W, H, spp, depth)
+    assert_planes_equal(out["xyz"], ref["xyz"], "seed %d XYZ" % seed)
+    assert_planes_equal(out["fb"], ref["fb"], "seed %d fb" % seed)
+    st, rs = out["stats"], ref["stats"]
+    assert st["rays"] == rs["rays"]
+    n_nan = st["util"][2]
+    assert st["node_visits"] + n_nan * (n - 1) == rs["trav_iters"] and st["tri_tests"] + n_nan * n == rs["tri_tests"]
