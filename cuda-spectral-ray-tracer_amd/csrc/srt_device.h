@@ -399,11 +399,11 @@ __device__ __forceinline__ int stack_exchange(const StackRef &st, int sp, int to
     return below;
 }
 __device__ __forceinline__ void trav_advance(Trav &tv, bool trav_l, bool trav_r, int lref, int rref, int below) {
-    const bool both = trav_l & trav_r, none = !(trav_l | trav_r);
+    const bool both = trav_l && trav_r, none = !trav_l && !trav_r;
     const int top = tv.top;
     tv.node = trav_l ? lref : (trav_r ? rref : top);
     tv.top = both ? rref : (none ? below : top);
-    tv.sp = tv.sp + (both ? 1 : 0) - (none ? 1 : 0);
+    tv.sp += both ? 1 : (none ? -1 : 0);
 }
 
 // Visit of an INNER record (both children internal): two box tests, no triangle work.  ALL_CACHED: the whole inner tree is
