@@ -1,14 +1,17 @@
 // srt_kernels.hip -- hand-written gfx950 kernels of the spectral path tracer.
 //
 // render_kernel is the whole hot path of the reference's spectral_render_kernel
-// (rendering/rendering.cu:151-235): one lane = one pixel, one wave = one 8x8 pixel tile,
-// samples and bounces looped inside the lane so the per-pixel XORWOW stream is consumed in the
-// reference's order.  Unlike the reference (one thread per pixel walking a pointer tree with a
-// 64-entry local-memory stack and a 36-byte hit record in shared memory) the lane is a small state
-// machine: paths are regenerated in place, the whole wave stays in the traversal loop while any lane
-// still has nodes to visit (64-bit __ballot), the traversal stack lives in LDS (one column per lane,
-// lane-interleaved so a push/pop is bank-conflict free), BVH nodes are 64-byte paired-child records
-// fetched with four coalesced-per-lane 16-byte loads, and the hit record is just (t, triangle).
+// (rendering/rendering.cu:151-235).  A lane owns one pixel at a time and consumes that pixel's XORWOW
+// stream in the reference's order (samples and bounces looped inside the lane); a wave pulls pixels
+// from a cost-ordered queue (8x8 tiles, split into narrower rows when a launch is chain-bound).
+// Unlike the reference (one thread per pixel walking a pointer tree with a 64-entry local-memory stack
+// and a 36-byte hit record in shared memory) the lane is a small state machine and the wave a scheduler:
+// shading passes (scatter, path end, new camera ray) alternate with branch-free traversal steps of two
+// kinds -- INNER records (two child boxes, the whole inner tree LDS resident when it fits) and FRINGE
+// records (a leaf child: box + triangle tests from one 96-byte record of (left, right) pairs) -- and
+// the wave serves whichever kind has the most waiting lanes per unit of cost.  The traversal stack lives
+// in LDS (one column per lane, lane-interleaved, newest entry in a register) and the hit record is just
+// (t, triangle).  DESIGN.md section 5 has the measurements behind every one of these choices.
 //
 // Build: hipcc --offload-arch=gfx950 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt
 #include <algorithm>
