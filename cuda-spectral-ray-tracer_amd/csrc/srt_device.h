@@ -217,7 +217,7 @@ struct TravStats {
 
 struct Trav {
     int node;        // >= 0: record to visit next; kTravDone (-1): query finished, result not yet shaded; kTravIdle (-2): no query
-    int sp;          // stack entries in use
+    uint32_t sp;     // LDS byte address of slot `entries in use` of this lane's stack column (the address IS the counter: no multiply, no add)
     int top;         // the newest stack entry lives in a register; -1 when the stack is empty.  LDS holds entries 0 .. sp-2
     float c;         // closest_so_far
     int hit;         // triangle of the closest hit or -1
@@ -227,8 +227,8 @@ constexpr int kTravDone = -1, kTravIdle = -2;
 
 // Start a closest-hit query (bvh.cu:101-119).  Returns true when the query is already finished (leaf root).
 template <bool COUNT>
-__device__ __forceinline__ bool trav_begin(Trav &tv, const float4 *__restrict__ tris, int root_ref, V3 o, V3 d, TravStats &ts) {
-    tv.c = kFltMax; tv.hit = -1; tv.sp = 0; tv.top = -1;
+__device__ __forceinline__ bool trav_begin(Trav &tv, uint32_t stack_base, const float4 *__restrict__ tris, int root_ref, V3 o, V3 d, TravStats &ts) {
+    tv.c = kFltMax; tv.hit = -1; tv.sp = stack_base; tv.top = -1;
     // A direction with a NaN component can never hit anything: every product with it is NaN (0*NaN included), so
     // dot(n, dir) is NaN, `fabs(denom) < 1e-8` is false, t = x/NaN is NaN and `0 <= t` is false for EVERY triangle
     // (tri.cu:12-23), while every box test passes (all comparisons false, aabb.cu:30-36).  The reference therefore
@@ -391,19 +391,26 @@ __device__ __forceinline__ void box_pair(const BoxPairs &b, V3 o, V3 inv, float 
 //     while the entry lives in the register; with sp = 0 it re-writes the sentinel -1).
 // Then  pop : node = top, top = below, sp-1      push : node = lref, top = rref, sp+1      else : node = the one child hit.
 // A pop from the empty stack yields node = top = -1 = kTravDone.
+// (`sp` is the LDS address of slot `entries in use`; StackRef only tells where an empty stack starts)
+template <bool NARROW> constexpr int kStackStride = NARROW ? 128 : 256;      // 64 lanes x 2 or 4 bytes per slot
+typedef __attribute__((address_space(3))) char lds_char;
 template <bool NARROW>
-__device__ __forceinline__ int stack_exchange(const StackRef &st, int sp, int top) {
+__device__ __forceinline__ uint32_t stack_base(const StackRef &st) { return NARROW ? (uint32_t)(uintptr_t)st.s16 : (uint32_t)(uintptr_t)st.s32; }
+template <bool NARROW>
+__device__ __forceinline__ int stack_exchange(uint32_t sp, int top) {
+    lds_char *slot = (lds_char *)(uintptr_t)sp;
     int below;
-    if (NARROW) { below = (int)st.s16[sp * 64]; st.s16[(sp + 1) * 64] = (int16_t)top; }
-    else { below = st.s32[sp * 64]; st.s32[(sp + 1) * 64] = top; }
+    if (NARROW) { below = (int)*(lds_i16 *)slot; *(lds_i16 *)(slot + 128) = (int16_t)top; }
+    else { below = *(lds_i32 *)slot; *(lds_i32 *)(slot + 256) = top; }
     return below;
 }
+template <bool NARROW>
 __device__ __forceinline__ void trav_advance(Trav &tv, bool trav_l, bool trav_r, int lref, int rref, int below) {
     const bool both = trav_l && trav_r, none = !trav_l && !trav_r;
     const int top = tv.top;
     tv.node = trav_l ? lref : (trav_r ? rref : top);
     tv.top = both ? rref : (none ? below : top);
-    tv.sp += both ? 1 : (none ? -1 : 0);
+    tv.sp += (uint32_t)(both ? kStackStride<NARROW> : (none ? -kStackStride<NARROW> : 0));
 }
 
 // Visit of an INNER record (both children internal): two box tests, no triangle work.  ALL_CACHED: the whole inner tree is
@@ -412,7 +419,7 @@ template <bool COUNT, bool NARROW, bool ALL_CACHED>
 __device__ __forceinline__ void trav_step_inner(Trav &tv, const NodeSrc &ns, V3 o, V3 inv, const StackRef &stack, TravStats &ts) {
     BoxPairs b;
     int lref, rref;
-    const int below = stack_exchange<NARROW>(stack, tv.sp, tv.top);
+    const int below = stack_exchange<NARROW>(tv.sp, tv.top);
     if (ALL_CACHED) {
         const uint32_t node = (uint32_t)tv.node, rec = node << 4;
         const uint32_t ax = rec + tv.nf[0], ay = rec + tv.nf[1], az = rec + tv.nf[2];
@@ -431,7 +438,7 @@ __device__ __forceinline__ void trav_step_inner(Trav &tv, const NodeSrc &ns, V3 
     const float c = tv.c;
     const bool trav_l = !(fminf(c, m_l) <= e_l);
     const bool trav_r = !(fminf(c, m_r) <= e_r);
-    trav_advance(tv, trav_l, trav_r, lref, rref, below);
+    trav_advance<NARROW>(tv, trav_l, trav_r, lref, rref, below);
 }
 
 // Visit of a FRINGE record (at least one leaf child), in two halves so that a caller can put independent work (a burst of
@@ -444,9 +451,9 @@ __device__ __forceinline__ void trav_fringe_fetch(FringeFetch &ff, const Trav &t
     const uint32_t off = __umul24((uint32_t)(tv.node - ns.n_inner), 96u);   // (full-rate 24-bit multiply; < 2^24 fringe records)
     ff.q0 = buf_load16(ns.global_fringe, off); ff.q1 = buf_load16(ns.global_fringe, off + 16u); ff.q2 = buf_load16(ns.global_fringe, off + 32u);
     ff.q3 = buf_load16(ns.global_fringe, off + 48u); ff.q4 = buf_load16(ns.global_fringe, off + 64u); ff.q5 = buf_load16(ns.global_fringe, off + 80u);
-    ff.below = stack_exchange<NARROW>(stack, tv.sp, tv.top);
+    ff.below = stack_exchange<NARROW>(tv.sp, tv.top);
 }
-template <bool COUNT>
+template <bool COUNT, bool NARROW>
 __device__ __forceinline__ void trav_fringe_compute(const FringeFetch &ff, Trav &tv, V3 o, V3 d, V3 inv, TravStats &ts) {
     const f4v q0 = ff.q0, q1 = ff.q1, q2 = ff.q2, q3 = ff.q3, q4 = ff.q4, q5 = ff.q5;
     const int below = ff.below;
@@ -504,13 +511,13 @@ __device__ __forceinline__ void trav_fringe_compute(const FringeFetch &ff, Trav 
     const bool trav_r = !leaf_r & !(fminf(c1, m_r) <= e_r);
     tv.c = c2;
     tv.hit = hit_r ? ~rref : (hit_l ? ~lref : tv.hit);
-    trav_advance(tv, trav_l, trav_r, lref, rref, below);
+    trav_advance<NARROW>(tv, trav_l, trav_r, lref, rref, below);
 }
 template <bool COUNT, bool NARROW>
 __device__ __forceinline__ void trav_step_fringe(Trav &tv, const NodeSrc &ns, V3 o, V3 d, V3 inv, const StackRef &stack, TravStats &ts) {
     FringeFetch ff;
     trav_fringe_fetch<NARROW>(ff, tv, ns, stack);
-    trav_fringe_compute<COUNT>(ff, tv, o, d, inv, ts);
+    trav_fringe_compute<COUNT, NARROW>(ff, tv, o, d, inv, ts);
 }
 
 }  // namespace srt

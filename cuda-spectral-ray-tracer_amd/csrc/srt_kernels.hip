@@ -194,7 +194,7 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
     float pw[kWavelengths];
 #pragma unroll
     for (int k = 0; k < kWavelengths; k++) pw[k] = 0.f;
-    Trav tv; tv.node = kTravIdle; tv.sp = 0; tv.top = -1; tv.c = kFltMax; tv.hit = -1; tv.nf[0] = tv.nf[1] = tv.nf[2] = 0u;
+    Trav tv; tv.node = kTravIdle; tv.sp = 0u; tv.top = -1; tv.c = kFltMax; tv.hit = -1; tv.nf[0] = tv.nf[1] = tv.nf[2] = 0u;
     uint32_t n_rays = 0;
     TravStats ts;
     // Rows of an expensive tile that was split over several waves (see order_tiles_kernel) are exclusive: the lanes whose
@@ -469,7 +469,7 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
                 n_rays++;
                 inv = mk(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);           // aabb.cu:17, hoisted out of the box test
                 ray_near_addresses(ns, inv, tv.nf);
-                (void)trav_begin<ITERS>(tv, P.tris, P.root_ref, ro, rd, ts);   // a query that finishes at once leaves kTravDone
+                (void)trav_begin<ITERS>(tv, stack_base<NARROW>(my_stack), P.tris, P.root_ref, ro, rd, ts);   // a query that finishes at once leaves kTravDone
             }
         }
 
@@ -712,16 +712,16 @@ __global__ __launch_bounds__(64) void trace_rays_kernel(const RenderParams P, co
     V3 o = mk(0, 0, 0), d = mk(0, 0, 1);
     if (active) { o = mk(rays[6 * k + 0], rays[6 * k + 1], rays[6 * k + 2]); d = mk(rays[6 * k + 3], rays[6 * k + 4], rays[6 * k + 5]); }
     TravStats ts;
-    Trav tv; tv.node = kTravIdle; tv.sp = 0; tv.top = -1; tv.c = kFltMax; tv.hit = -1; tv.nf[0] = tv.nf[1] = tv.nf[2] = 0u;
+    Trav tv; tv.node = kTravIdle; tv.sp = 0u; tv.top = -1; tv.c = kFltMax; tv.hit = -1; tv.nf[0] = tv.nf[1] = tv.nf[2] = 0u;
     const V3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    if (active) trav_begin<false>(tv, P.tris, P.root_ref, o, d, ts);
+    StackRef my_stack; my_stack.s16 = nullptr; my_stack.s32 = (lds_i32 *)s_stack + lane;
+    stack_init<false>(my_stack);
+    if (active) trav_begin<false>(tv, stack_base<false>(my_stack), P.tris, P.root_ref, o, d, ts);
     NodeSrc ns;
     ns.global_nodes = make_rsrc(P.nodes, (uint32_t)P.n_inner * 64u);
     ns.global_fringe = make_rsrc(P.fringe, (uint32_t)(P.n_records - P.n_inner) * 96u);
     ns.n_inner = P.n_inner;
     ns.lds_q0 = ns.lds_q1 = ns.lds_q2 = nullptr; ns.lds_r0 = ns.lds_r1 = nullptr; ns.n_cached = 0;
-    StackRef my_stack; my_stack.s16 = nullptr; my_stack.s32 = (lds_i32 *)s_stack + lane;
-    stack_init<false>(my_stack);
     while (__ballot(tv.node >= 0) != 0ull) {
         if (tv.node >= P.n_inner) trav_step_fringe<false, false>(tv, ns, o, d, inv, my_stack, ts);
         else if (tv.node >= 0) trav_step_inner<false, false, false>(tv, ns, o, inv, my_stack, ts);   // n_cached = 0: global records
