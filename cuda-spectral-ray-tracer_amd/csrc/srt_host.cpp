@@ -355,6 +355,7 @@ int flatten_scene(const srt_scene &s, FlatScene &out) {
     for (size_t k = 0; k < n_tris; k++)
         if (s.raw[k].mat_index >= n_mats) { set_global_error("upload: triangle references a missing material"); return SRT_ERR_INVALID; }
     if (n_mats >= (1u << 23)) { set_global_error("upload: too many materials"); return SRT_ERR_INVALID; }
+    if (n_tris >= (1u << 24)) { set_global_error("upload: too many triangles (record offsets are formed with 24-bit multiplies)"); return SRT_ERR_INVALID; }
 
     // triangles: a = {n, D}, b = {v0[w], v0[h], v1[w], v1[h]}, c = {v2[w], v2[h], flags, 0}
     out.tris.assign(12 * n_tris, 0.f);

@@ -234,7 +234,7 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
                 } else {
                     // rebuild the hit record from (t, triangle): tri::hit tail (tri.cu:36-39) + set_face_normal.  ONE round of
                     // loads: the triangle's shading record carries the normal, the material index and the material scalars.
-                    const uint32_t srec = (uint32_t)tv.hit * 48u;
+                    const uint32_t srec = __umul24((uint32_t)tv.hit, 48u);      // (full-rate 24-bit multiply; < 2^24 triangles)
                     const f4v s0 = buf_load16(shade_rsrc, srec), s1 = buf_load16(shade_rsrc, srec + 16u), s2 = buf_load16(shade_rsrc, srec + 32u);
                     const V3 n_geo = mk(s0.x, s0.y, s0.z);
                     const V3 hp = ro + tv.c * rd;                                          // ray::at, ray.cuh:31-34
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
                 // per-wavelength `if (k < valid)` would put seven dependent memory round trips one after the other.
                 const bool ends_here = !was_hit || !hit_scattered;
                 const float delta_lambda = (kLambdaMax - kLambdaMin) / (float)kWavelengths;
-                const uint32_t sd_base = sd_table * 768u;
+                const uint32_t sd_base = __umul24(sd_table, 768u);
                 int off[kWavelengths];
                 float wgt[kWavelengths];
                 float2 sp[kWavelengths];
