@@ -506,7 +506,8 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
             const uint32_t s_fr = n_fringe * P.score_fringe;
             const uint32_t s_in = (n_trav - n_fringe) << 8;
             if (s_sh > max(s_fr, s_in)) break;
-            const bool do_fringe = s_fr > s_in || n_fringe == n_trav;   // (every traversing lane at a fringe record: always progress)
+            // (when every traversing lane sits at a fringe record, s_in = 0 < s_fr because the weight is >= 1: always progress)
+            const bool do_fringe = s_fr > s_in;
             if (COUNT) { ts.w_iters++; ts.w_alive += n_alive; if (do_fringe) { ts.w_fringe++; ts.l_fringe += n_fringe; } else ts.l_inner += n_trav - n_fringe; }
             if (do_fringe) {
                 if (tv.node >= (int)n_inner_u) trav_step_fringe<ITERS, NARROW>(tv, ns, ro, rd, inv, my_stack, ts);
