@@ -53,7 +53,7 @@ constexpr size_t kLdsBudget = 160 * 1024;
 #define SRT_INNER_BURST 8
 #endif
 #ifndef SRT_BURST_DROP
-#define SRT_BURST_DROP 2
+#define SRT_BURST_DROP 3
 #endif
 constexpr int kInnerBurst = SRT_INNER_BURST;   // at most this many inner steps between two scheduling decisions (fully unrolled)
 constexpr uint32_t kBurstDrop = SRT_BURST_DROP;   // ... and the burst ends once fewer than 1 / kBurstDrop of its lanes are still at inner records
@@ -527,7 +527,8 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
                     if (m == 0ull) break;
                     // leave early once most of the lanes the burst started with have moved on (fringe record, finished query):
                     // the remaining few are better served together with the lanes a new decision brings in
-                    // (burst 4 / 8 with drop 2: 424.5 / 420.0 ms on cfg 3)
+                    // (bursts of 8: exit below 75 / 67 / 50 / 40 / 33 / 25 / 14 % of the starting lanes: 410 / 406 / 396 / 392 / 391 / 393 / 402 ms
+                    // on cfg 3; testing only every second step: 412 ms; a decision after every step: 429 ms)
                     if ((uint32_t)__popcll(m) * kBurstDrop < (n_trav - n_fringe)) break;
                 }
                 if (COUNT) { const unsigned long long now = __builtin_amdgcn_s_memtime(); t_inner += now - t_mark; t_mark = now; }
