@@ -517,6 +517,9 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
                 // are a sizeable part of a 60-instruction step.  `at_inner` is carried across the back edge so that one
                 // compare serves the step's EXEC mask and the loop exit.
                 bool at_inner = (uint32_t)tv.node < n_inner_u;
+                // the burst ends when fewer than `stay` lanes remain: ceil(lanes at the start / kBurstDrop), at least 1 -- so the
+                // test also covers "no lane left" and costs a popcount and a compare per step
+                const uint32_t stay = (n_trav - n_fringe + kBurstDrop - 1u) / kBurstDrop;
 #pragma unroll
                 for (int burst = 0; burst < kInnerBurst; burst++) {
                     if (at_inner) trav_step_inner<ITERS, NARROW, ALL_CACHED>(tv, ns, ro, inv, my_stack, ts);
@@ -524,12 +527,11 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
                     const unsigned long long m = __ballot(at_inner);
                     if (COUNT && burst > 0) { ts.w_iters++; ts.w_alive += n_alive; }
                     if (COUNT && burst < kInnerBurst - 1) ts.l_inner += (uint32_t)__popcll(m);
-                    if (m == 0ull) break;
                     // leave early once most of the lanes the burst started with have moved on (fringe record, finished query):
                     // the remaining few are better served together with the lanes a new decision brings in
                     // (bursts of 8: exit below 75 / 67 / 50 / 40 / 33 / 25 / 14 % of the starting lanes: 410 / 406 / 396 / 392 / 391 / 393 / 402 ms
                     // on cfg 3; testing only every second step: 412 ms; a decision after every step: 429 ms)
-                    if ((uint32_t)__popcll(m) * kBurstDrop < (n_trav - n_fringe)) break;
+                    if ((uint32_t)__popcll(m) < stay) break;
                 }
                 if (COUNT) { const unsigned long long now = __builtin_amdgcn_s_memtime(); t_inner += now - t_mark; t_mark = now; }
             }
