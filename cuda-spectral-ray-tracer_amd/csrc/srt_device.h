@@ -464,16 +464,21 @@ __device__ __forceinline__ void trav_fringe_compute(const FringeFetch &ff, Trav 
     const bool leaf_l = lref < 0, leaf_r = rref < 0;
     if (COUNT) { ts.n_iters++; ts.n_tri += (leaf_l ? 1u : 0u) + (leaf_r ? 1u : 0u); ts.n_box += (leaf_l ? 0u : 1u) + (leaf_r ? 0u : 1u); }
 
-    // ---- both child boxes (words 0-5 = xmin xmax ymin ymax zmin zmax); a leaf child's words hold a triangle, its box result
-    // is ignored ------------------------------------------------------------------------------------------------------
-    float e_l, m_l, e_r, m_r;
+    // ---- the box of the internal child (words 0-5 = xmin xmax ymin ymax zmin zmax of its block).  A FRINGE record has at
+    // least one leaf child, so at most ONE child has a box: one scalar slab test on the right child's words when the right
+    // child is internal, on the left child's otherwise (both leaves: the result is ignored) -- half the arithmetic of the
+    // paired test of an INNER record.  aabb::hit (aabb.cu:7-40) as in box_pair: e = max(tmin, t0x, t0y, t0z), m = min(t1x, t1y, t1z).
+    float e_box, m_box;
     {
+        const bool int_r = !leaf_r;
+        const float xlo = int_r ? w0.y : w0.x, xhi = int_r ? w1.y : w1.x, ylo = int_r ? w2.y : w2.x, yhi = int_r ? w3.y : w3.x;
+        const float zlo = int_r ? w4.y : w4.x, zhi = int_r ? w5.y : w5.x;
         const bool px = inv.x >= 0, py = inv.y >= 0, pz = inv.z >= 0;
-        BoxPairs b;
-        b.nx = px ? w0 : w1; b.fx = px ? w1 : w0;
-        b.ny = py ? w2 : w3; b.fy = py ? w3 : w2;
-        b.nz = pz ? w4 : w5; b.fz = pz ? w5 : w4;
-        box_pair(b, o, inv, e_l, m_l, e_r, m_r);
+        const float t0x = ((px ? xlo : xhi) - o.x) * inv.x, t1x = ((px ? xhi : xlo) - o.x) * inv.x;
+        const float t0y = ((py ? ylo : yhi) - o.y) * inv.y, t1y = ((py ? yhi : ylo) - o.y) * inv.y;
+        const float t0z = ((pz ? zlo : zhi) - o.z) * inv.z, t1z = ((pz ? zhi : zlo) - o.z) * inv.z;
+        e_box = fmaxf(fmaxf(fmaxf(0.0f, t0x), t0y), t0z);
+        m_box = fminf(fminf(t1x, t1y), t1z);
     }
 
     // ---- both leaf triangles in one segment (words 0-9 = n.x n.y n.z D v0w v0h v1w v1h v2w v2h; a fringe record has at
@@ -505,10 +510,13 @@ __device__ __forceinline__ void trav_fringe_compute(const FringeFetch &ff, Trav 
     const float c0 = tv.c;
     const bool hit_l = ok_l & (t.x <= c0);
     const float c1 = hit_l ? t.x : c0;
-    const bool trav_l = !leaf_l & !(fminf(c0, m_l) <= e_l);
     const bool hit_r = ok_r & (t.y <= c1);
     const float c2 = hit_r ? t.y : c1;
-    const bool trav_r = !leaf_r & !(fminf(c1, m_r) <= e_r);
+    // the one box: an internal LEFT child is tested with c0 (before anything on the right), an internal RIGHT child with c1 (after
+    // the left leaf's hit, if any)
+    const bool pass = !(fminf(leaf_r ? c0 : c1, m_box) <= e_box);
+    const bool trav_l = !leaf_l & pass;
+    const bool trav_r = !leaf_r & pass;
     tv.c = c2;
     tv.hit = hit_r ? ~rref : (hit_l ? ~lref : tv.hit);
     trav_advance<NARROW>(tv, trav_l, trav_r, lref, rref, below);
