@@ -451,7 +451,8 @@ __device__ __forceinline__ void trav_fringe_fetch(FringeFetch &ff, const Trav &t
     const uint32_t off = __umul24((uint32_t)(tv.node - ns.n_inner), 96u);   // (full-rate 24-bit multiply; < 2^24 fringe records)
     ff.q0 = buf_load16(ns.global_fringe, off); ff.q1 = buf_load16(ns.global_fringe, off + 16u); ff.q2 = buf_load16(ns.global_fringe, off + 32u);
     ff.q3 = buf_load16(ns.global_fringe, off + 48u); ff.q4 = buf_load16(ns.global_fringe, off + 64u); ff.q5 = buf_load16(ns.global_fringe, off + 80u);
-    ff.below = stack_exchange<NARROW>(tv.sp, tv.top);
+    // a FRINGE visit never pushes (at most one child is internal), so it only needs the entry a pop would bring up
+    ff.below = NARROW ? (int)*(lds_i16 *)(uintptr_t)tv.sp : *(lds_i32 *)(uintptr_t)tv.sp;
 }
 template <bool COUNT, bool NARROW>
 __device__ __forceinline__ void trav_fringe_compute(const FringeFetch &ff, Trav &tv, V3 o, V3 d, V3 inv, TravStats &ts) {
@@ -515,11 +516,14 @@ __device__ __forceinline__ void trav_fringe_compute(const FringeFetch &ff, Trav 
     // the one box: an internal LEFT child is tested with c0 (before anything on the right), an internal RIGHT child with c1 (after
     // the left leaf's hit, if any)
     const bool pass = !(fminf(leaf_r ? c0 : c1, m_box) <= e_box);
-    const bool trav_l = !leaf_l & pass;
-    const bool trav_r = !leaf_r & pass;
     tv.c = c2;
     tv.hit = hit_r ? ~rref : (hit_l ? ~lref : tv.hit);
-    trav_advance<NARROW>(tv, trav_l, trav_r, lref, rref, below);
+    // bvh.cu:154-160 with at most one traversable child: descend into it, or pop; never a push
+    const bool go = !(leaf_l & leaf_r) & pass;
+    const int top = tv.top;
+    tv.node = go ? (leaf_r ? lref : rref) : top;
+    tv.top = go ? top : below;
+    tv.sp += (uint32_t)(go ? 0 : -kStackStride<NARROW>);
 }
 template <bool COUNT, bool NARROW>
 __device__ __forceinline__ void trav_step_fringe(Trav &tv, const NodeSrc &ns, V3 o, V3 d, V3 inv, const StackRef &stack, TravStats &ts) {
