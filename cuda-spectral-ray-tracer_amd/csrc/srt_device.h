@@ -82,22 +82,32 @@ __device__ __forceinline__ uint32_t rng_next(Rng &s) {
     s.d += 362437u;
     return s.v4 + s.d;
 }
-// cuda_random_float(): curand_uniform in (0,1]  (utils/cuda_utility.cu:19-26)
-__device__ __forceinline__ float rng_uniform(Rng &s) {
-    return (float)rng_next(s) * 2.3283064e-10f + (2.3283064e-10f / 2.0f);
+// cuda_random_float(): curand_uniform in (0,1]  (utils/cuda_utility.cu:19-26): fl(fl(v * 2^-32) + 2^-33) with v = (float)r.
+// v * 2^-32 is exact (a power-of-two scaling of an fp32 value in [0, 2^32], no underflow), so ONE fused multiply-add
+// rounds exactly where the reference's add rounds: same bits for every r (checked on the device: op sweep, op 18).
+__device__ __forceinline__ float rng_unit_from_bits(uint32_t r) {
+    return __builtin_fmaf((float)r, 2.3283064e-10f, 2.3283064e-10f / 2.0f);
 }
+__device__ __forceinline__ float rng_uniform(Rng &s) { return rng_unit_from_bits(rng_next(s)); }
 // cuda_random_float(min,max): u*(max-min)+min  (utils/cuda_utility.cu:28-41)
 __device__ __forceinline__ float rng_range(Rng &s, float mn, float mx) {
     float range_width = mx - mn;
     float random = rng_uniform(s);
     return random * range_width + mn;
 }
+// cuda_random_float(-1, 1) = fl(fl(u * 2) + -1): u * 2 is exact, and 2 * fl(v * 2^-32 + 2^-33) = fl(v * 2^-31 + 2^-32)
+// (scaling by two commutes with rounding, nothing here is near the denormal range), again one fused operation with an
+// exact product; the final add is the reference's (op sweep, op 19).
+__device__ __forceinline__ float rng_pm1_from_bits(uint32_t r) {
+    return __builtin_fmaf((float)r, 2.0f * 2.3283064e-10f, 2.3283064e-10f) + -1.0f;
+}
+__device__ __forceinline__ float rng_pm1(Rng &s) { return rng_pm1_from_bits(rng_next(s)); }
 // random_in_unit_sphere (math/vec3.cuh:210-218); draws x, y, z in that order (DESIGN.md D1 / SURVEY Q19)
 __device__ __forceinline__ V3 random_in_unit_sphere(Rng &s) {
     for (;;) {
-        float x = rng_range(s, -1.0f, 1.0f);
-        float y = rng_range(s, -1.0f, 1.0f);
-        float z = rng_range(s, -1.0f, 1.0f);
+        float x = rng_pm1(s);
+        float y = rng_pm1(s);
+        float z = rng_pm1(s);
         V3 p = mk(x, y, z);
         if (length_squared(p) < 1.0f) return p;
     }
@@ -531,5 +541,6 @@ __device__ __forceinline__ void trav_step_fringe(Trav &tv, const NodeSrc &ns, V3
     trav_fringe_fetch<NARROW>(ff, tv, ns, stack);
     trav_fringe_compute<COUNT, NARROW>(ff, tv, o, d, inv, ts);
 }
+
 
 }  // namespace srt

@@ -443,8 +443,8 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
                 if (!(U->defocus_angle <= 0.0f)) {                          // defocus_disk_sample, :42-47
                     float dx, dy;
                     for (;;) {                                             // random_in_unit_disk, vec3.cuh:240-246
-                        dx = rng_range(rs, -1.0f, 1.0f);
-                        dy = rng_range(rs, -1.0f, 1.0f);
+                        dx = rng_pm1(rs);
+                        dy = rng_pm1(rs);
                         if ((dx * dx + dy * dy) + 0.0f * 0.0f < 1.0f) break;
                     }
                     origin = (cam_center + dx * mk(U->disk_u[0], U->disk_u[1], U->disk_u[2])) +
@@ -772,6 +772,8 @@ __global__ void op_sweep_kernel(int which, const float *a, const float *b, uint3
     case 15: { f2 a2 = mk2(x, y), b2 = mk2(y, x * 0.5f); f2 c2 = a2 + b2; r = (k & 1) ? c2.y : c2.x; } break;    // v_pk_add_f32
     case 16: { f2 a2 = mk2(x, y), b2 = mk2(y, x); f2 c2 = (a2 - b2) * x - a2 * b2; r = (k & 1) ? c2.y : c2.x; } break;
     case 17: r = srt_pow5f(x); break;                  // must equal dev_powf(x, 5)
+    case 18: r = rng_unit_from_bits(__float_as_uint(x)); break;   // must equal (float)r * 2^-32 + 2^-33 in two roundings
+    case 19: r = rng_pm1_from_bits(__float_as_uint(x)); break;    // must equal ((float)r * 2^-32 + 2^-33) * 2 + -1
     default: r = 0.f;
     }
     out[k] = r;

@@ -50,6 +50,13 @@ def test_primitive_op_sweep(gpu, orc):
     # u32 -> f32 (RNG mapping) and the truncating cast used by spectrum_interp / expand_sRGB
     got = gpu.op_sweep(12, a, b)
     assert _same(got, a.view(np.uint32).astype(np.float32))
+    # the fused forms of the uniform mapping (one fma with an exact product) equal the reference's mul-then-add forms
+    r = np.concatenate([rng.integers(0, 1 << 32, n - 4096, dtype=np.uint64).astype(np.uint32),
+                        np.arange(2048, dtype=np.uint32), np.uint32(0xffffffff) - np.arange(2048, dtype=np.uint32)])
+    rf = r.astype(np.float32)
+    u = rf * np.float32(2.3283064e-10) + np.float32(2.3283064e-10) / np.float32(2.0)
+    assert _same(gpu.op_sweep(18, r.view(np.float32), b), u)
+    assert _same(gpu.op_sweep(19, r.view(np.float32), b), u * np.float32(2.0) + np.float32(-1.0))
     small = (rng.random(n).astype(np.float32) * 600.0 - 100.0).astype(np.float32)
     assert _same(gpu.op_sweep(7, small, b), np.trunc(small).astype(np.int32).astype(np.float32))
 

@@ -21,3 +21,9 @@ for rep in range(2):
     best = min(best, r.last_kernel_ms())
 st = r.stats()
 print("lane_limit", os.environ.get("SRT_DEBUG_LANE_LIMIT", "64"), "ms %.1f" % best, "rays", st["rays"], "max_pixel_node_visits", st.get("max_pixel_node_visits"))
+print("  shade counters", list(st["shade"]))
+if a.count:
+    u = st["util"]; n_in, n_fr = u[0] - u[3], u[3]
+    tot = max(u[6] + u[7] + u[8], 1)
+    print("  instrumented: inner steps %d (%.0f cyc each), fringe steps %d (%.0f cyc each), shading passes %d (%.0f cyc each); shares shade/inner/fringe %.2f %.2f %.2f; cycles per ray %.0f" %
+          (n_in, u[7] / max(n_in, 1), n_fr, u[8] / max(n_fr, 1), st["shade"][0], u[6] / max(st["shade"][0], 1), u[6] / tot, u[7] / tot, u[8] / tot, tot / max(st["rays"], 1)))
