@@ -451,6 +451,142 @@ __device__ __forceinline__ void trav_step_inner(Trav &tv, const NodeSrc &ns, V3 
     trav_advance<NARROW>(tv, trav_l, trav_r, lref, rref, below);
 }
 
+// A burst of up to eight INNER visits in hand-scheduled gfx950 assembly (production build, 16-bit references, whole inner tree
+// in LDS).  Instruction for instruction the visit the compiler makes of trav_step_inner -- the same loads, the same packed
+// subtractions / products / min / max / compares in the same operand order, the same selects -- but the bookkeeping around it is
+// cheaper than anything the compiler will emit for `if (at_inner) step`:
+//   * EXEC only ever shrinks inside a burst (a lane that leaves the inner records does not come back before the next
+//     scheduling decision), so it is saved once, narrowed by the v_cmpx that tests `still at an inner record` and restored
+//     once -- no s_and_saveexec / s_cbranch_execz / s_or exec per visit;
+//   * the two wait states between the compare that writes a lane mask and the select that reads it are filled with work;
+//   * LDS returns data in issue order, so three partial s_waitcnt let the x products start while the y and z planes are
+//     still in flight (a third of a wave's life was spent in s_waitcnt);
+//   * origin and reciprocal direction are read from three register pairs with op_sel broadcasts instead of six splat pairs.
+// The burst ends after eight visits or as soon as fewer than `stay` lanes are still at inner records (stay >= 1), exactly like
+// the C++ loop in render_kernel.  Registers v100-v118 and s80-s86 are scratch.
+#ifndef SRT_ASM_SPLIT_WAIT
+#define SRT_ASM_SPLIT_WAIT 1
+#endif
+// LDS returns data in issue order, so the x products can start while the y / z planes are still in flight
+#if SRT_ASM_SPLIT_WAIT == 2
+#define SRT_LDS_ORDER_A
+#define SRT_LDS_ORDER_B
+#define SRT_LDS_ORDER_C "ds_read_i16 v116, %[sp]\n\t" "v_lshl_add_u32 v112, %[node], 2, %[refs]\n\t" "ds_read_b32 v112, v112\n\t"
+#define SRT_WAIT_X "s_waitcnt lgkmcnt(6)\n\t"
+#define SRT_WAIT_Y "s_waitcnt lgkmcnt(4)\n\t"
+#define SRT_WAIT_Z "s_waitcnt lgkmcnt(2)\n\t"
+#define SRT_WAIT_END "s_waitcnt lgkmcnt(0)\n\t"
+#else
+#define SRT_LDS_ORDER_A "ds_read_i16 v116, %[sp]\n\t"
+#define SRT_LDS_ORDER_B "v_lshl_add_u32 v112, %[node], 2, %[refs]\n\t" "ds_read_b32 v112, v112\n\t"
+#define SRT_LDS_ORDER_C
+#define SRT_WAIT_END
+#if SRT_ASM_SPLIT_WAIT == 1
+#define SRT_WAIT_X "s_waitcnt lgkmcnt(5)\n\t"
+#define SRT_WAIT_Y "s_waitcnt lgkmcnt(2)\n\t"
+#define SRT_WAIT_Z "s_waitcnt lgkmcnt(0)\n\t"
+#else
+#define SRT_WAIT_X "s_waitcnt lgkmcnt(0)\n\t"
+#define SRT_WAIT_Y
+#define SRT_WAIT_Z
+#endif
+#endif
+#define SRT_INNER_VISIT_ASM                                                                                              \
+    "v_lshlrev_b32 v112, 4, %[node]\n\t"                                                                                 \
+    "ds_write_b16 %[sp], %[top] offset:128\n\t"                                                                          \
+    "v_add_u32 v113, v112, %[nf0]\n\t"                             /* near pair addresses of the three axes */           \
+    "v_add_u32 v114, v112, %[nf1]\n\t"                                                                                   \
+    "v_add_u32 v115, v112, %[nf2]\n\t"                                                                                   \
+    "ds_read_b64 v[100:101], v113\n\t"                                                                                   \
+    "v_xor_b32 v113, 8, v113\n\t"                                  /* far pair = the other half of the plane entry */    \
+    SRT_LDS_ORDER_A                                                                                                      \
+    "ds_read_b64 v[102:103], v113\n\t"                                                                                   \
+    "ds_read_b64 v[104:105], v114\n\t"                                                                                   \
+    "v_xor_b32 v114, 8, v114\n\t"                                                                                        \
+    SRT_LDS_ORDER_B                                                                                                      \
+    "ds_read_b64 v[106:107], v114\n\t"                                                                                   \
+    "ds_read_b64 v[108:109], v115\n\t"                                                                                   \
+    "v_xor_b32 v115, 8, v115\n\t"                                                                                        \
+    "ds_read_b64 v[110:111], v115\n\t"                                                                                   \
+    SRT_LDS_ORDER_C                                                                                                      \
+    SRT_WAIT_X                                                                                                           \
+    "v_pk_add_f32 v[100:101], v[100:101], %[p0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t" /* near x - o.x */        \
+    "v_pk_add_f32 v[102:103], v[102:103], %[p0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t" /* far  x - o.x */        \
+    "v_pk_mul_f32 v[100:101], %[p1], v[100:101] op_sel:[1,0]\n\t"                              /* * inv.x */             \
+    "v_pk_mul_f32 v[102:103], %[p1], v[102:103] op_sel:[1,0]\n\t"                                                        \
+    SRT_WAIT_Y                                                                                                           \
+    "v_pk_add_f32 v[106:107], v[106:107], %[p0] op_sel:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"    /* far  y - o.y */        \
+    "v_pk_add_f32 v[104:105], v[104:105], %[p0] op_sel:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"    /* near y - o.y */        \
+    "v_pk_mul_f32 v[106:107], %[p2], v[106:107] op_sel_hi:[0,1]\n\t"                           /* * inv.y */             \
+    "v_pk_mul_f32 v[104:105], %[p2], v[104:105] op_sel_hi:[0,1]\n\t"                                                     \
+    SRT_WAIT_Z                                                                                                           \
+    "v_pk_add_f32 v[108:109], v[108:109], %[p1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t" /* near z - o.z */        \
+    "v_pk_add_f32 v[110:111], v[110:111], %[p1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t" /* far  z - o.z */        \
+    "v_pk_mul_f32 v[108:109], %[p2], v[108:109] op_sel:[1,0]\n\t"                              /* * inv.z */             \
+    "v_pk_mul_f32 v[110:111], %[p2], v[110:111] op_sel:[1,0]\n\t"                                                        \
+    "v_max_f32 v100, 0, v100\n\t"                                                                                        \
+    "v_min_f32 v102, v102, v106\n\t"                                                                                     \
+    "v_max3_f32 v100, v100, v104, v108\n\t"                        /* e_l */                                             \
+    "v_max_f32 v101, 0, v101\n\t"                                                                                        \
+    "v_min_f32 v103, v103, v107\n\t"                                                                                     \
+    "v_min3_f32 v102, %[c], v102, v110\n\t"                        /* min(c, m_l) */                                     \
+    "v_max3_f32 v101, v101, v105, v109\n\t"                        /* e_r */                                             \
+    "v_cmp_nle_f32 vcc, v102, v100\n\t"                            /* trav_l */                                          \
+    "v_min3_f32 v100, %[c], v103, v111\n\t"                        /* min(c, m_r) */                                     \
+    "v_cmp_nle_f32_e64 s[82:83], v100, v101\n\t"                   /* trav_r */                                          \
+    SRT_WAIT_END                                                                                                         \
+    "v_lshrrev_b32 v117, 16, v112\n\t"                             /* rref */                                            \
+    "s_or_b64 s[84:85], vcc, s[82:83]\n\t"                         /* any */                                             \
+    "v_cndmask_b32_e64 v118, %[top], v117, s[82:83]\n\t"                                                                 \
+    "v_cndmask_b32_sdwa %[node], v118, v112, vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n\t" \
+    "s_and_b64 vcc, vcc, s[82:83]\n\t"                             /* both */                                            \
+    "v_cndmask_b32_e64 v118, %[ms], 0, s[84:85]\n\t"                                                                     \
+    "v_cndmask_b32_e64 %[top], v116, %[top], s[84:85]\n\t"                                                               \
+    "v_cndmask_b32_e32 v118, v118, %[ps], vcc\n\t"                                                                       \
+    "v_cndmask_b32_e32 %[top], %[top], v117, vcc\n\t"                                                                    \
+    "v_add_u32 %[sp], v118, %[sp]\n\t"
+#ifndef SRT_ASM_CMPX
+#define SRT_ASM_CMPX 1
+#endif
+#if SRT_ASM_CMPX
+// v_cmpx narrows EXEC itself (and writes VCC, which nothing reads)
+#define SRT_INNER_NEXT_ASM                                                                                               \
+    "v_cmpx_gt_u32 vcc, %[ninner], %[node]\n\t"                                                                          \
+    "s_bcnt1_i32_b64 s86, exec\n\t"                                                                                      \
+    "s_cmp_lt_u32 s86, %[stay]\n\t"                                                                                      \
+    "s_cbranch_scc1 .Lsrt_burst_end%=\n\t"
+#else
+#define SRT_INNER_NEXT_ASM                                                                                               \
+    "v_cmp_gt_u32 vcc, %[ninner], %[node]\n\t"                                                                           \
+    "s_bcnt1_i32_b64 s86, vcc\n\t"                                                                                       \
+    "s_cmp_lt_u32 s86, %[stay]\n\t"                                                                                      \
+    "s_cbranch_scc1 .Lsrt_burst_end%=\n\t"                                                                               \
+    "s_mov_b64 exec, vcc\n\t"
+#endif
+__device__ __forceinline__ void inner_burst8_asm(Trav &tv, const NodeSrc &ns, V3 o, V3 inv, uint32_t n_inner, uint32_t stay) {
+    const f2 p0 = mk2(o.x, o.y), p1 = mk2(o.z, inv.x), p2 = mk2(inv.y, inv.z);
+    const int minus_stride = -kStackStride<true>, plus_stride = kStackStride<true>;
+    const uint32_t refs = (uint32_t)(uintptr_t)ns.lds_r0;
+    asm volatile(
+        "s_mov_b64 s[80:81], exec\n\t"
+        "v_cmpx_gt_u32 vcc, %[ninner], %[node]\n\t"
+        SRT_INNER_VISIT_ASM SRT_INNER_NEXT_ASM
+        SRT_INNER_VISIT_ASM SRT_INNER_NEXT_ASM
+        SRT_INNER_VISIT_ASM SRT_INNER_NEXT_ASM
+        SRT_INNER_VISIT_ASM SRT_INNER_NEXT_ASM
+        SRT_INNER_VISIT_ASM SRT_INNER_NEXT_ASM
+        SRT_INNER_VISIT_ASM SRT_INNER_NEXT_ASM
+        SRT_INNER_VISIT_ASM SRT_INNER_NEXT_ASM
+        SRT_INNER_VISIT_ASM
+        ".Lsrt_burst_end%=:\n\t"
+        "s_mov_b64 exec, s[80:81]\n\t"
+        : [node] "+v"(tv.node), [top] "+v"(tv.top), [sp] "+v"(tv.sp)
+        : [nf0] "v"(tv.nf[0]), [nf1] "v"(tv.nf[1]), [nf2] "v"(tv.nf[2]), [p0] "v"(p0), [p1] "v"(p1), [p2] "v"(p2), [c] "v"(tv.c),
+          [ms] "v"(minus_stride), [ps] "v"(plus_stride), [ninner] "s"(n_inner), [refs] "s"(refs), [stay] "s"(stay)
+        : "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114",
+          "v115", "v116", "v117", "v118", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "vcc", "scc", "memory");
+}
+
 // Visit of a FRINGE record (at least one leaf child), in two halves so that a caller can put independent work (a burst of
 // INNER steps for other lanes of the wave) between the loads and their first use: the record comes from L2, several hundred
 // cycles away.

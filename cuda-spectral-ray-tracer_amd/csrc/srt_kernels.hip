@@ -55,6 +55,9 @@ constexpr size_t kLdsBudget = 160 * 1024;
 #ifndef SRT_BURST_DROP
 #define SRT_BURST_DROP 3
 #endif
+#ifndef SRT_ASM_BURST
+#define SRT_ASM_BURST 1
+#endif
 constexpr int kInnerBurst = SRT_INNER_BURST;   // at most this many inner steps between two scheduling decisions (fully unrolled)
 constexpr uint32_t kBurstDrop = SRT_BURST_DROP;   // ... and the burst ends once fewer than 1 / kBurstDrop of its lanes are still at inner records
 static inline size_t round16(size_t v) { return (v + 15) & ~(size_t)15; }
@@ -520,6 +523,9 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
                 // the burst ends when fewer than `stay` lanes remain: ceil(lanes at the start / kBurstDrop), at least 1 -- so the
                 // test also covers "no lane left" and costs a popcount and a compare per step
                 const uint32_t stay = (n_trav - n_fringe + kBurstDrop - 1u) / kBurstDrop;
+                if (!ITERS && NARROW && ALL_CACHED && kInnerBurst == 8 && SRT_ASM_BURST) {
+                    inner_burst8_asm(tv, ns, ro, inv, n_inner_u, stay);      // the same eight visits, hand-scheduled (srt_device.h)
+                } else
 #pragma unroll
                 for (int burst = 0; burst < kInnerBurst; burst++) {
                     if (at_inner) trav_step_inner<ITERS, NARROW, ALL_CACHED>(tv, ns, ro, inv, my_stack, ts);
