@@ -429,6 +429,11 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
                         }
                     }
                 }
+                // Drain this block's memory traffic here, once per pixel: its stores and generic-pointer (flat) accesses share
+                // the vmcnt / lgkmcnt counters with the record loads of the traversal loop and complete out of order with
+                // respect to them, so anything that MAY still be in flight makes the compiler wait for vmcnt(0) at the first
+                // load result a FRINGE visit uses -- all six record loads before touching the first one.
+                __builtin_amdgcn_s_waitcnt(0x0070);      // vmcnt(0) lgkmcnt(0)
             }
 
             // ---- S4: new camera ray: renderer::get_ray (rendering.cu:66-87) ----------------------------------------
