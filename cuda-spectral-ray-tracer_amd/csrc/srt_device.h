@@ -587,6 +587,68 @@ __device__ __forceinline__ void inner_burst8_asm(Trav &tv, const NodeSrc &ns, V3
           "v115", "v116", "v117", "v118", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "vcc", "scc", "memory");
 }
 
+// The scheduling decision of render_kernel's traversal phase together with the INNER bursts it leads to, in one block:
+//   repeat { count the lanes waiting for a shading pass / at a fringe record / at an inner record; weigh them (the same
+//            unsigned arithmetic as the C++ loop: waiting * score_shade, fringe * score_fringe, inner << 8);
+//            shading wins -> return 0;  fringe wins -> return 1;  else one burst of up to eight INNER visits }
+// so that a burst costs one decision (14 scalar instructions) and no trip through compiler-generated control flow; the
+// caller only runs the FRINGE visit (C++) when 1 comes back.  `stay` of a burst = ceil(inner lanes / 3) (kBurstDrop = 3).
+#define SRT_INNER_NEXT2_ASM                                                                                              \
+    "v_cmpx_gt_u32 vcc, %[ninner], %[node]\n\t"                                                                          \
+    "s_bcnt1_i32_b64 s86, exec\n\t"                                                                                      \
+    "s_cmp_lt_u32 s86, s87\n\t"                                                                                          \
+    "s_cbranch_scc1 .Lsrt_phase_burst_end%=\n\t"
+__device__ __forceinline__ uint32_t inner_phase_asm(Trav &tv, const NodeSrc &ns, V3 o, V3 inv, uint32_t n_inner, uint32_t n_alive,
+                                                    uint32_t score_shade, uint32_t score_fringe) {
+    const f2 p0 = mk2(o.x, o.y), p1 = mk2(o.z, inv.x), p2 = mk2(inv.y, inv.z);
+    const int minus_stride = -kStackStride<true>, plus_stride = kStackStride<true>;
+    const uint32_t refs = (uint32_t)(uintptr_t)ns.lds_r0;
+    uint32_t kind;
+    asm volatile(
+        "s_mov_b64 s[80:81], exec\n\t"
+        ".Lsrt_phase_decide%=:\n\t"
+        "v_cmp_lt_i32 vcc, -1, %[node]\n\t"                          /* traversing */
+        "v_cmp_le_i32_e64 s[82:83], %[ninner], %[node]\n\t"          /* ... at a fringe record */
+        "s_bcnt1_i32_b64 s86, vcc\n\t"
+        "s_bcnt1_i32_b64 s87, s[82:83]\n\t"
+        "s_sub_u32 s88, %[nalive], s86\n\t"                          /* lanes waiting for a shading pass */
+        "s_sub_u32 s86, s86, s87\n\t"                                /* lanes at an inner record */
+        "s_mul_i32 s88, s88, %[wshade]\n\t"
+        "s_mul_i32 s89, s87, %[wfringe]\n\t"
+        "s_lshl_b32 s84, s86, 8\n\t"
+        "s_max_u32 s85, s89, s84\n\t"
+        "s_mov_b32 %[kind], 0\n\t"
+        "s_cmp_gt_u32 s88, s85\n\t"
+        "s_cbranch_scc1 .Lsrt_phase_end%=\n\t"                       /* shading pass (or nothing traversing) */
+        "s_mov_b32 %[kind], 1\n\t"
+        "s_cmp_gt_u32 s89, s84\n\t"
+        "s_cbranch_scc1 .Lsrt_phase_end%=\n\t"                       /* FRINGE visit */
+        "s_add_u32 s87, s86, 2\n\t"                                  /* stay = ceil(inner lanes / 3) */
+        "s_mul_hi_u32 s87, s87, 0xaaaaaaab\n\t"
+        "s_lshr_b32 s87, s87, 1\n\t"
+        "s_andn2_b64 exec, vcc, s[82:83]\n\t"                        /* the lanes at inner records */
+        SRT_INNER_VISIT_ASM SRT_INNER_NEXT2_ASM
+        SRT_INNER_VISIT_ASM SRT_INNER_NEXT2_ASM
+        SRT_INNER_VISIT_ASM SRT_INNER_NEXT2_ASM
+        SRT_INNER_VISIT_ASM SRT_INNER_NEXT2_ASM
+        SRT_INNER_VISIT_ASM SRT_INNER_NEXT2_ASM
+        SRT_INNER_VISIT_ASM SRT_INNER_NEXT2_ASM
+        SRT_INNER_VISIT_ASM SRT_INNER_NEXT2_ASM
+        SRT_INNER_VISIT_ASM
+        ".Lsrt_phase_burst_end%=:\n\t"
+        "s_mov_b64 exec, s[80:81]\n\t"
+        "s_branch .Lsrt_phase_decide%=\n\t"
+        ".Lsrt_phase_end%=:\n\t"
+        : [node] "+v"(tv.node), [top] "+v"(tv.top), [sp] "+v"(tv.sp), [kind] "=&s"(kind)
+        : [nf0] "v"(tv.nf[0]), [nf1] "v"(tv.nf[1]), [nf2] "v"(tv.nf[2]), [p0] "v"(p0), [p1] "v"(p1), [p2] "v"(p2), [c] "v"(tv.c),
+          [ms] "v"(minus_stride), [ps] "v"(plus_stride), [ninner] "s"(n_inner), [refs] "s"(refs), [nalive] "s"(n_alive),
+          [wshade] "s"(score_shade), [wfringe] "s"(score_fringe)
+        : "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114",
+          "v115", "v116", "v117", "v118", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "vcc",
+          "scc", "memory");
+    return kind;
+}
+
 // Visit of a FRINGE record (at least one leaf child), in two halves so that a caller can put independent work (a burst of
 // INNER steps for other lanes of the wave) between the loads and their first use: the record comes from L2, several hundred
 // cycles away.

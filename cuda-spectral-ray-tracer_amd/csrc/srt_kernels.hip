@@ -56,7 +56,7 @@ constexpr size_t kLdsBudget = 160 * 1024;
 #define SRT_BURST_DROP 3
 #endif
 #ifndef SRT_ASM_BURST
-#define SRT_ASM_BURST 1
+#define SRT_ASM_BURST 2      /* 0: C++ bursts, 1: assembly bursts, 2: assembly decision + bursts */
 #endif
 constexpr int kInnerBurst = SRT_INNER_BURST;   // at most this many inner steps between two scheduling decisions (fully unrolled)
 constexpr uint32_t kBurstDrop = SRT_BURST_DROP;   // ... and the burst ends once fewer than 1 / kBurstDrop of its lanes are still at inner records
@@ -176,6 +176,10 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
     const buf_rsrc shade_rsrc = make_rsrc(P.shade, P.n_tris * 48u);
     const buf_rsrc sd_rsrc = make_rsrc(P.mat_sd, (P.n_materials + 1u) * 768u);
     const uint32_t spp = P.spp;
+    // the step-choice weights as opaque register values: read from the kernel arguments once, not re-loaded (an s_load and a
+    // wait) every time the traversal loop comes round
+    uint32_t w_shade = P.score_shade, w_fringe = P.score_fringe;
+    asm volatile("" : "+s"(w_shade), "+s"(w_fringe));
     StackRef my_stack;
     {
         const size_t slots = (size_t)(P.stack_depth < 1 ? 1 : P.stack_depth) + kStackSentinels;
@@ -502,6 +506,13 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
             }
             continue;
         }
+        if (!ITERS && NARROW && ALL_CACHED && kInnerBurst == 8 && kBurstDrop == 3u && SRT_ASM_BURST == 2) {
+            // production build: the decision below and the INNER bursts it leads to are one assembly block (inner_phase_asm,
+            // srt_device.h -- the same arithmetic); only the FRINGE visits come back here
+            while (inner_phase_asm(tv, ns, ro, inv, n_inner_u, n_alive, w_shade, w_fringe) != 0u) {
+                if (tv.node >= (int)n_inner_u) trav_step_fringe<ITERS, NARROW>(tv, ns, ro, rd, inv, my_stack, ts);
+            }
+        } else
         for (;;) {
             // Serve the kind of work with the most waiting lanes per unit of step cost (weights = 256 / relative cost of the
             // step, srt_capi.cpp).  Traversing lanes are alive (a lane retires or parks only between queries), so the lanes
@@ -528,7 +539,7 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
                 // the burst ends when fewer than `stay` lanes remain: ceil(lanes at the start / kBurstDrop), at least 1 -- so the
                 // test also covers "no lane left" and costs a popcount and a compare per step
                 const uint32_t stay = (n_trav - n_fringe + kBurstDrop - 1u) / kBurstDrop;
-                if (!ITERS && NARROW && ALL_CACHED && kInnerBurst == 8 && SRT_ASM_BURST) {
+                if (!ITERS && NARROW && ALL_CACHED && kInnerBurst == 8 && SRT_ASM_BURST == 1) {
                     inner_burst8_asm(tv, ns, ro, inv, n_inner_u, stay);      // the same eight visits, hand-scheduled (srt_device.h)
                 } else
 #pragma unroll
