@@ -1,6 +1,7 @@
 """GPU parity tests proper: the HIP path (through the C-ABI) against the CPU oracle on the same seeded inputs.
 Bar: bit-exact fp32 (stronger than BASELINE's 1e-3 L-inf, which is asserted as well)."""
 import importlib
+import os
 import numpy as np
 import pytest
 
@@ -328,6 +329,36 @@ def test_full_size_blocks_bit_exact(srt, gpu, orc):
     # lanes the oracle did not render stay zero there; the GPU image is complete: no pixel of the image is left unwritten
     rm = gpu.read_fb_rowmajor(W, H)
     assert min(float(p.max()) for p in rm) > 0 and all(np.isfinite(p).all() for p in rm)
+
+
+@pytest.mark.skipif(os.environ.get("SRT_LONG") != "1", reason="several minutes of oracle time on all host cores: SRT_LONG=1 to run")
+def test_full_frame_full_spp_bit_exact(srt, gpu, orc):
+    """The WHOLE headline frame (random-spheres scene, 1920x1080, 1024 spp, depth 16: every one of the 4 692 blocks, 5.2 G
+    rays) against the oracle, bit for bit.  Opt-in (SRT_LONG=1): ~7 minutes of oracle time on 256 host threads.  Result of
+    the last run: profiles/r02/full_frame_parity.txt."""
+    import sys, time
+    W, H, spp, depth = 1920, 1080, int(os.environ.get("SRT_LONG_SPP", "1024")), 16
+    scene = srt.Scene.builtin(srt.SCENE_RANDOM_SPHERES, 0).build_bvh(srt.BVH_SAH)
+    cam = scene.default_camera(W, H)
+    gpu.upload_scene(scene); gpu.set_camera(cam); gpu.set_partition(0, 1)
+    gpu.init_device_params(W, H, spp, depth, 1984)
+    gpu.set_count_traversal(False)
+    gpu.render_chunk(W, H)
+    gpu.scatter_tiles()
+    fb, xyz = gpu.read_fb(), gpu.read_fb_aux(2)
+    n_blocks = gpu.geom["bx"] * gpu.geom["by"]
+    osc = oracle_scene_for(orc, scene, 1)
+    threads = os.cpu_count() or 1
+    slices, differing, checked, t0 = 16, 0, 0, time.time()
+    for k in range(slices):                           # the oracle in slices, so that a long run keeps printing
+        ref = osc.render(cam, W, H, spp, depth, block_lo=k, block_stride=slices, threads=threads)
+        for b in range(k, n_blocks, slices):
+            sl = slice(b * 448, (b + 1) * 448)
+            for c in range(3):
+                differing += int(np.sum(bits(xyz[c][sl]) != bits(ref["xyz"][c][sl]))) + int(np.sum(fb[c][sl] != ref["fb"][c][sl]))
+            checked += 1
+        print("slice %d/%d: %d blocks checked, %d differing values, %.0f s" % (k + 1, slices, checked, differing, time.time() - t0), file=sys.stderr, flush=True)
+    assert checked == n_blocks and differing == 0
 
 
 def _blocks_bit_exact(srt, gpu, orc, sid, mode, W, H, spp, depth, block_lo, stride, max_blocks):
