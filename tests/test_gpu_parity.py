@@ -337,8 +337,11 @@ def test_full_frame_full_spp_bit_exact(srt, gpu, orc):
     rays) against the oracle, bit for bit.  Opt-in (SRT_LONG=1): ~7 minutes of oracle time on 256 host threads.  Result of
     the last run: profiles/r02/full_frame_parity.txt."""
     import sys, time
-    W, H, spp, depth = 1920, 1080, int(os.environ.get("SRT_LONG_SPP", "1024")), 16
-    scene = srt.Scene.builtin(srt.SCENE_RANDOM_SPHERES, 0).build_bvh(srt.BVH_SAH)
+    cfg = os.environ.get("SRT_LONG_CFG", "3")          # 3: the headline frame; 2: cfg 2's frame; 5: cfg 5's scene at 3840x2160, 64 spp
+    sid, W, H, spp = {"2": (srt.SCENE_RANDOM_SPHERES, 1280, 720, 256), "3": (srt.SCENE_RANDOM_SPHERES, 1920, 1080, 1024),
+                      "5": (srt.SCENE_MESH100K, 3840, 2160, 64)}[cfg]
+    spp, depth = int(os.environ.get("SRT_LONG_SPP", str(spp))), 16
+    scene = srt.Scene.builtin(sid, 0).build_bvh(srt.BVH_SAH)
     cam = scene.default_camera(W, H)
     gpu.upload_scene(scene); gpu.set_camera(cam); gpu.set_partition(0, 1)
     gpu.init_device_params(W, H, spp, depth, 1984)
