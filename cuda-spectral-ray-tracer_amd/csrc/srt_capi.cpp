@@ -255,8 +255,10 @@ int srt_render_chunk(srt_ctx *c, uint32_t width, uint32_t height, uint32_t offx,
         int wpb = 1, n_cached = 0;
         render_launch_shape(c->stack_depth, c->n_records, c->n_inner, wpb, n_cached);
         const bool all_cached = n_cached == c->n_inner;
-        p.score_shade = c->score_shade ? c->score_shade : (all_cached ? 70u : 140u);
-        p.score_fringe = c->score_fringe ? c->score_fringe : (all_cached ? 280u : 560u);
+        // (inner records that come from L2 make an INNER visit ~2x as expensive, so shading and FRINGE visits weigh more:
+        // plateau 280-400 / 560-1100 on cfg 5's scene, 60-85 / 280-340 on cfg 2 / 3 / 4, profiles/r02/knob_sweeps.txt)
+        p.score_shade = c->score_shade ? c->score_shade : (all_cached ? 70u : 320u);
+        p.score_fringe = c->score_fringe ? c->score_fringe : (all_cached ? 280u : 800u);
     }
     // ---- cost-ordered pixel queue --------------------------------------------------------------------------------
     // A pixel is one sequential RNG stream, so the launch cannot finish before its most expensive pixel does.  A short
