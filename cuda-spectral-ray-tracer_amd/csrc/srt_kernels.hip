@@ -58,6 +58,17 @@ constexpr size_t kLdsBudget = 160 * 1024;
 #ifndef SRT_ASM_BURST
 #define SRT_ASM_BURST 2      /* 0: C++ bursts, 1: assembly bursts, 2: assembly decision + bursts */
 #endif
+#ifndef SRT_INNER_BURST_L2
+#define SRT_INNER_BURST_L2 4
+#endif
+#ifndef SRT_BURST_DROP_L2
+#define SRT_BURST_DROP_L2 2
+#endif
+// ... when part of the inner tree comes from L2 (ALL_CACHED false) a visit is twice as long and shorter bursts that end at half of
+// their lanes win: 4 / 2 (sweep on cfg 5's scene, 64 spp: 8/3 238.3, 4/3 230.8, 12/3 244.6, 8/2 231.8, 8/5 243.3, 2/2 237.2, 3/2 234.8,
+// 4/2 229.9, 6/2 230.4, 4/1 246.0 ms)
+constexpr int kInnerBurstL2 = SRT_INNER_BURST_L2;
+constexpr uint32_t kBurstDropL2 = SRT_BURST_DROP_L2;
 constexpr int kInnerBurst = SRT_INNER_BURST;   // at most this many inner steps between two scheduling decisions (fully unrolled)
 constexpr uint32_t kBurstDrop = SRT_BURST_DROP;   // ... and the burst ends once fewer than 1 / kBurstDrop of its lanes are still at inner records
 static inline size_t round16(size_t v) { return (v + 15) & ~(size_t)15; }
@@ -538,17 +549,19 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
                 bool at_inner = (uint32_t)tv.node < n_inner_u;
                 // the burst ends when fewer than `stay` lanes remain: ceil(lanes at the start / kBurstDrop), at least 1 -- so the
                 // test also covers "no lane left" and costs a popcount and a compare per step
-                const uint32_t stay = (n_trav - n_fringe + kBurstDrop - 1u) / kBurstDrop;
+                constexpr int burst_len = ALL_CACHED ? kInnerBurst : kInnerBurstL2;
+                constexpr uint32_t burst_drop = ALL_CACHED ? kBurstDrop : kBurstDropL2;
+                const uint32_t stay = (n_trav - n_fringe + burst_drop - 1u) / burst_drop;
                 if (!ITERS && NARROW && ALL_CACHED && kInnerBurst == 8 && SRT_ASM_BURST == 1) {
                     inner_burst8_asm(tv, ns, ro, inv, n_inner_u, stay);      // the same eight visits, hand-scheduled (srt_device.h)
                 } else
 #pragma unroll
-                for (int burst = 0; burst < kInnerBurst; burst++) {
+                for (int burst = 0; burst < burst_len; burst++) {
                     if (at_inner) trav_step_inner<ITERS, NARROW, ALL_CACHED>(tv, ns, ro, inv, my_stack, ts);
                     at_inner = (uint32_t)tv.node < n_inner_u;
                     const unsigned long long m = __ballot(at_inner);
                     if (COUNT && burst > 0) { ts.w_iters++; ts.w_alive += n_alive; }
-                    if (COUNT && burst < kInnerBurst - 1) ts.l_inner += (uint32_t)__popcll(m);
+                    if (COUNT && burst < burst_len - 1) ts.l_inner += (uint32_t)__popcll(m);
                     // leave early once most of the lanes the burst started with have moved on (fringe record, finished query):
                     // the remaining few are better served together with the lanes a new decision brings in
                     // (bursts of 8: exit below 75 / 67 / 50 / 40 / 33 / 25 / 14 % of the starting lanes: 410 / 406 / 396 / 392 / 391 / 393 / 402 ms
