@@ -51,6 +51,10 @@ __device__ __forceinline__ V3 refract(V3 uv, V3 n, float etai_over_etat) {
     V3 r_out_parallel = (-sqrtf(fabsf(1.0f - length_squared(r_out_perp)))) * n;
     return r_out_perp + r_out_parallel;
 }
+// IEEE-754-2019 minimum (v_minimum3_f32 on gfx950): a NaN operand makes the result NaN, -0 < +0.  `a >= 0 && b >= 0 && c >= 0`
+// is `minimum(minimum(a, b), c) >= 0` for every operand (a NaN fails both forms, zeros of either sign pass both): two instructions
+// and one compare instead of three compares and two mask operations (trav_fringe_compute's inside test).
+
 __device__ __forceinline__ bool near_zero(V3 v) {   // :93-98
     const float s = 1e-8f;
     return (fabsf(v.x) < s) && (fabsf(v.y) < s) && (fabsf(v.z) < s);
@@ -707,10 +711,14 @@ __device__ __forceinline__ void trav_fringe_compute(const FringeFetch &ff, Trav 
     // `-a >= 0` for every float (zeros of either sign pass both, NaN fails both), and -a is a flip of the sign bit, which the
     // record holds in bit 31 of the flags word for counter-clockwise triangles: one code path, no branch.
     const uint32_t sl = fl & 0x80000000u, sr = fr & 0x80000000u;
-    const bool in_l = (__uint_as_float(__float_as_uint(a1.x) ^ sl) >= 0.f) & (__uint_as_float(__float_as_uint(a2.x) ^ sl) >= 0.f) &
-                      (__uint_as_float(__float_as_uint(a3.x) ^ sl) >= 0.f);
-    const bool in_r = (__uint_as_float(__float_as_uint(a1.y) ^ sr) >= 0.f) & (__uint_as_float(__float_as_uint(a2.y) ^ sr) >= 0.f) &
-                      (__uint_as_float(__float_as_uint(a3.y) ^ sr) >= 0.f);
+    // (all three >= 0  <=>  their NaN-propagating minimum >= 0)
+    // (two steps, pinned: holding all three flipped areas of both triangles for one three-operand minimum costs registers the
+    // kernel does not have)
+    float m_l = __builtin_elementwise_minimum(__uint_as_float(__float_as_uint(a1.x) ^ sl), __uint_as_float(__float_as_uint(a2.x) ^ sl));
+    float m_r = __builtin_elementwise_minimum(__uint_as_float(__float_as_uint(a1.y) ^ sr), __uint_as_float(__float_as_uint(a2.y) ^ sr));
+    asm volatile("" : "+v"(m_l), "+v"(m_r));
+    const bool in_l = __builtin_elementwise_minimum(m_l, __uint_as_float(__float_as_uint(a3.x) ^ sl)) >= 0.f;
+    const bool in_r = __builtin_elementwise_minimum(m_r, __uint_as_float(__float_as_uint(a3.y) ^ sr)) >= 0.f;
     // plane not parallel, t >= tmin, inside (everything but `t <= c`)
     const bool ok_l = leaf_l & !(fabsf(denom.x) < 1e-8f) & (0.0f <= t.x) & in_l;
     const bool ok_r = leaf_r & !(fabsf(denom.y) < 1e-8f) & (0.0f <= t.y) & in_r;
