@@ -55,6 +55,16 @@ __device__ __forceinline__ V3 refract(V3 uv, V3 n, float etai_over_etat) {
 // is `minimum(minimum(a, b), c) >= 0` for every operand (a NaN fails both forms, zeros of either sign pass both): two instructions
 // and one compare instead of three compares and two mask operations (trav_fringe_compute's inside test).
 
+// The two halves of that test as the FRINGE visit uses them (`sign` = 0 for a clockwise triangle, 0x80000000 for a
+// counter-clockwise one: `a <= 0` is `-a >= 0`, a flip of the sign bit); op-sweep kinds 20 / 21 run exactly these two functions
+// against the three compares of is_interior_faster (primitives/tri.cu:121-128).
+__device__ __forceinline__ float inside_min2(float a1, float a2, uint32_t sign) {
+    return __builtin_elementwise_minimum(__uint_as_float(__float_as_uint(a1) ^ sign), __uint_as_float(__float_as_uint(a2) ^ sign));
+}
+__device__ __forceinline__ bool inside_min3(float m12, float a3, uint32_t sign) {
+    return __builtin_elementwise_minimum(m12, __uint_as_float(__float_as_uint(a3) ^ sign)) >= 0.f;
+}
+
 __device__ __forceinline__ bool near_zero(V3 v) {   // :93-98
     const float s = 1e-8f;
     return (fabsf(v.x) < s) && (fabsf(v.y) < s) && (fabsf(v.z) < s);
@@ -714,11 +724,11 @@ __device__ __forceinline__ void trav_fringe_compute(const FringeFetch &ff, Trav 
     // (all three >= 0  <=>  their NaN-propagating minimum >= 0)
     // (two steps, pinned: holding all three flipped areas of both triangles for one three-operand minimum costs registers the
     // kernel does not have)
-    float m_l = __builtin_elementwise_minimum(__uint_as_float(__float_as_uint(a1.x) ^ sl), __uint_as_float(__float_as_uint(a2.x) ^ sl));
-    float m_r = __builtin_elementwise_minimum(__uint_as_float(__float_as_uint(a1.y) ^ sr), __uint_as_float(__float_as_uint(a2.y) ^ sr));
+    float m_l = inside_min2(a1.x, a2.x, sl);
+    float m_r = inside_min2(a1.y, a2.y, sr);
     asm volatile("" : "+v"(m_l), "+v"(m_r));
-    const bool in_l = __builtin_elementwise_minimum(m_l, __uint_as_float(__float_as_uint(a3.x) ^ sl)) >= 0.f;
-    const bool in_r = __builtin_elementwise_minimum(m_r, __uint_as_float(__float_as_uint(a3.y) ^ sr)) >= 0.f;
+    const bool in_l = inside_min3(m_l, a3.x, sl);
+    const bool in_r = inside_min3(m_r, a3.y, sr);
     // plane not parallel, t >= tmin, inside (everything but `t <= c`)
     const bool ok_l = leaf_l & !(fabsf(denom.x) < 1e-8f) & (0.0f <= t.x) & in_l;
     const bool ok_r = leaf_r & !(fabsf(denom.y) < 1e-8f) & (0.0f <= t.y) & in_r;

@@ -787,6 +787,7 @@ __global__ void op_sweep_kernel(int which, const float *a, const float *b, uint3
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     const float x = a[k], y = b[k];
+    const float z = a[(k ^ 1u) < n ? (k ^ 1u) : k];      // third operand of kinds 20 / 21
     float r;
     switch (which) {
     case 0: r = x + y; break;
@@ -809,6 +810,10 @@ __global__ void op_sweep_kernel(int which, const float *a, const float *b, uint3
     case 17: r = srt_pow5f(x); break;                  // must equal dev_powf(x, 5)
     case 18: r = rng_unit_from_bits(__float_as_uint(x)); break;   // must equal (float)r * 2^-32 + 2^-33 in two roundings
     case 19: r = rng_pm1_from_bits(__float_as_uint(x)); break;    // must equal ((float)r * 2^-32 + 2^-33) * 2 + -1
+    // the inside test of the FRINGE visit (NaN-propagating minimum, sign flip for counter-clockwise triangles) on the operand
+    // triple (a[k], b[k], a[k ^ 1]): must equal the three compares of is_interior_faster (tri.cu:121-128)
+    case 20: { float m = inside_min2(x, y, 0u); asm volatile("" : "+v"(m)); r = inside_min3(m, z, 0u) ? 1.f : 0.f; } break;                      // a1 >= 0 && a2 >= 0 && a3 >= 0
+    case 21: { float m = inside_min2(x, y, 0x80000000u); asm volatile("" : "+v"(m)); r = inside_min3(m, z, 0x80000000u) ? 1.f : 0.f; } break;    // a1 <= 0 && a2 <= 0 && a3 <= 0
     default: r = 0.f;
     }
     out[k] = r;

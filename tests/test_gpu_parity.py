@@ -58,6 +58,20 @@ def test_primitive_op_sweep(gpu, orc):
     u = rf * np.float32(2.3283064e-10) + np.float32(2.3283064e-10) / np.float32(2.0)
     assert _same(gpu.op_sweep(18, r.view(np.float32), b), u)
     assert _same(gpu.op_sweep(19, r.view(np.float32), b), u * np.float32(2.0) + np.float32(-1.0))
+    # the FRINGE visit's inside test: NaN-propagating minimum (v_minimum3-style, with the sign-bit flip for counter-clockwise
+    # triangles) == the three compares of is_interior_faster (primitives/tri.cu:121-128) on 2^22 operand triples
+    # (a[k], b[k], a[k ^ 1]) incl. +-0, NaN, denormals, infinities -- and on a dense block of every special-value combination
+    sp = np.array([0.0, -0.0, np.nan, -np.nan, 1e-45, -1e-45, 1e-38, -1e-38, np.inf, -np.inf, 1.0, -1.0, 3.4028235e38, -3.4028235e38], np.float32)
+    a3, b3 = a.copy(), b.copy()
+    combos = np.array([(x, y, z) for x in sp for y in sp for z in sp], np.float32)          # 2744 triples at even k: third operand = a[k + 1]
+    a3[0:2 * combos.shape[0]:2] = combos[:, 0]; b3[0:2 * combos.shape[0]:2] = combos[:, 1]; a3[1:2 * combos.shape[0]:2] = combos[:, 2]
+    c3 = a3.reshape(-1, 2)[:, ::-1].reshape(-1)                                          # a[k ^ 1]
+    with np.errstate(all="ignore"):
+        want_cw = ((a3 >= 0) & (b3 >= 0) & (c3 >= 0)).astype(np.float32)
+        want_ccw = ((a3 <= 0) & (b3 <= 0) & (c3 <= 0)).astype(np.float32)
+    assert np.array_equal(gpu.op_sweep(20, a3, b3), want_cw)
+    assert np.array_equal(gpu.op_sweep(21, a3, b3), want_ccw)
+    assert 0 < want_cw.sum() < n and 0 < want_ccw.sum() < n
     small = (rng.random(n).astype(np.float32) * 600.0 - 100.0).astype(np.float32)
     assert _same(gpu.op_sweep(7, small, b), np.trunc(small).astype(np.int32).astype(np.float32))
 
@@ -99,11 +113,18 @@ SCENES = [
 ]
 
 
+# Every adversarial input goes through BOTH builds of render_kernel: the instrumented one (MODE 1: C++ traversal steps, work
+# counters) and the production one (MODE 0: the hand-scheduled assembly block for the INNER visits and the step choice when the
+# tree is narrow and LDS resident -- which all of these small scenes are -- i.e. the kernel that ships and that bench.py times).
+VARIANTS = [pytest.param(True, id="instrumented"), pytest.param(False, id="production")]
+
+
+@pytest.mark.parametrize("count_traversal", VARIANTS)
 @pytest.mark.parametrize("sid,mode,W,H,spp,depth", SCENES)
-def test_image_bit_exact(srt, gpu, orc, sid, mode, W, H, spp, depth):
+def test_image_bit_exact(srt, gpu, orc, sid, mode, W, H, spp, depth, count_traversal):
     scene = srt.Scene.builtin(sid, 0).build_bvh(mode, 1984)
     cam = scene.default_camera(W, H)
-    out = srt.render_image(scene, cam, W, H, spp, depth, renderer=gpu, count_traversal=True)
+    out = srt.render_image(scene, cam, W, H, spp, depth, renderer=gpu, count_traversal=count_traversal)
     ref = oracle_scene_for(orc, scene, mode).render(cam, W, H, spp, depth)
     assert_planes_equal(out["xyz"], ref["xyz"], "XYZ sums")
     assert_planes_equal(out["lin"], ref["lin"], "unquantised sRGB")
@@ -112,6 +133,8 @@ def test_image_bit_exact(srt, gpu, orc, sid, mode, W, H, spp, depth):
     assert linf <= 1e-3                     # BASELINE tolerance (per-channel L-inf on sRGB in [0,1])
     st, rs = out["stats"], ref["stats"]
     assert st["rays"] == rs["rays"] and st["paths"] == rs["paths"]
+    if not count_traversal:
+        return                              # the production build keeps no work counters
     # work counters: identical to the reference's, except that NaN-direction queries are answered without
     # walking the tree -- the reference visits every internal node and tests every triangle for them and finds nothing
     n_nan, n_tris = st["util"][2], scene.n_tris
@@ -514,8 +537,9 @@ def _custom_scene(srt, tris, mats, bg_rgb=(0.5, 0.5, 0.5)):
     return srt.Scene.from_arrays(T, M, bg)
 
 
+@pytest.mark.parametrize("count_traversal", VARIANTS)
 @pytest.mark.parametrize("case", ["one_triangle", "two_triangles", "degenerate_and_odd_materials", "forty_materials"])
-def test_custom_scenes_edge_cases(srt, gpu, orc, case):
+def test_custom_scenes_edge_cases(srt, gpu, orc, case, count_traversal):
     """Scenes that come in through srt_scene_set_* (not the built-ins): a BVH whose root is a leaf (bvh.cu:114-119), a two-leaf
     tree (one FRINGE record, no INNER record), zero-area / needle triangles (NaN normal: every test on them fails, as in the
     reference), material types the switch sends to its default branch (NO_MAT = 6, an unknown id), an emissive surface, and more
@@ -544,7 +568,7 @@ def test_custom_scenes_edge_cases(srt, gpu, orc, case):
     scene = _custom_scene(srt, tris, mats).build_bvh(srt.BVH_REFERENCE, 1984)
     W, H, spp, depth = 45, 37, 6, 6
     cam = srt.camera_init(W, H, 60.0, (0.3, 0.2, 9.0), (0.0, 0.0, 0.0))
-    out = srt.render_image(scene, cam, W, H, spp, depth, renderer=gpu, count_traversal=True)
+    out = srt.render_image(scene, cam, W, H, spp, depth, renderer=gpu, count_traversal=count_traversal)
     osc = oracle_scene_for(orc, scene, 0)
     ref = osc.render(cam, W, H, spp, depth)
     assert_planes_equal(out["xyz"], ref["xyz"], case + " XYZ")
@@ -554,8 +578,9 @@ def test_custom_scenes_edge_cases(srt, gpu, orc, case):
         assert max(float(p.max()) for p in out["xyz"]) > 0       # the camera sees something
 
 
+@pytest.mark.parametrize("count_traversal", VARIANTS)
 @pytest.mark.parametrize("seed", range(12))
-def test_random_scenes_fuzz(srt, gpu, orc, seed):
+def test_random_scenes_fuzz(srt, gpu, orc, seed, count_traversal):
     """Random triangle soups with random materials, cameras and builders (both BVH builders, lens on / off, thin and
     axis-aligned triangles, shared edges and vertices so that exact t ties occur -- Q11): GPU == oracle bit for bit,
     work counters included."""
@@ -587,11 +612,13 @@ def test_random_scenes_fuzz(srt, gpu, orc, seed):
     W, H, spp, depth = int(rng.integers(9, 70)), int(rng.integers(9, 50)), int(rng.integers(1, 7)), int(rng.integers(1, 17))
     cam = srt.camera_init(W, H, float(rng.uniform(20, 90)), tuple(rng.uniform(-12, 12, 3)), tuple(rng.uniform(-2, 2, 3)),
                           defocus_angle=float(rng.choice([0.0, 0.0, 1.5])), focus_dist=float(rng.uniform(5, 15)))
-    out = srt.render_image(scene, cam, W, H, spp, depth, renderer=gpu, count_traversal=True)
+    out = srt.render_image(scene, cam, W, H, spp, depth, renderer=gpu, count_traversal=count_traversal)
     ref = oracle_scene_for(orc, scene, mode).render(cam, W, H, spp, depth)
     assert_planes_equal(out["xyz"], ref["xyz"], "seed %d XYZ" % seed)
     assert_planes_equal(out["fb"], ref["fb"], "seed %d fb" % seed)
     st, rs = out["stats"], ref["stats"]
     assert st["rays"] == rs["rays"]
+    if not count_traversal:
+        return
     n_nan = st["util"][2]
     assert st["node_visits"] + n_nan * (n - 1) == rs["trav_iters"] and st["tri_tests"] + n_nan * n == rs["tri_tests"]
