@@ -44,7 +44,7 @@ class Stats(C.Structure):
 class Calibration(C.Structure):
     _fields_ = [("wave_cycles_mean", C.c_double), ("wave_cycles_max", C.c_double), ("wall_ms", C.c_double),
                 ("instr_per_wave", C.c_uint64), ("n_waves", C.c_uint32), ("n_cu", C.c_uint32), ("waves_per_simd", C.c_uint32),
-                ("reserved", C.c_uint32)]
+                ("reserved", C.c_uint32), ("wave_cycles_min", C.c_double)]
 
 
 assert C.sizeof(Material) == 428 and C.sizeof(CameraData) == 84 and C.sizeof(TriIn) == 44
@@ -71,6 +71,7 @@ PROTOTYPES = {
     "srt_material_bake": (_i, [C.POINTER(Material)]),
     "srt_bake_sigmoid_spectrum": (_i, [_fp, _f, _i, _fp]),
     "srt_fit_sigmoid_coeffs": (_i, [_fp, _fp]),
+    "srt_color_tables": (_i, [_fp, _fp]),
     "srt_background_spectrum": (_i, [_fp, _fp]),
     "srt_scene_build_bvh": (_i, [_vp, _i, _u64]),
     "srt_scene_node_count": (_sz, [_vp]),
@@ -85,6 +86,7 @@ PROTOTYPES = {
     "srt_set_partition": (_i, [_vp, _u32, _u32]),
     "srt_render_chunk": (_i, [_vp, _u32, _u32, _u32, _u32, _vp]),
     "srt_synchronize": (_i, [_vp]),
+    "srt_set_gather_planes": (_i, [_vp, _u32]),
     "srt_tile_buffer": (_i, [_vp, C.POINTER(_vp), C.POINTER(_sz), C.POINTER(_u32), C.POINTER(_u32)]),
     "srt_copy_tile_buffer": (_i, [_vp, _vp, _vp]),
     "srt_scatter_tiles": (_i, [_vp, _vp, _vp]),
@@ -103,6 +105,9 @@ PROTOTYPES = {
     "srt_comm_init_all": (_i, [C.POINTER(_i), _i, C.POINTER(_vp)]),
     "srt_comm_unique_id": (_i, [C.POINTER(C.c_ubyte)]),
     "srt_comm_init_rank": (_i, [_vp, C.POINTER(C.c_ubyte), _u32, _u32, C.POINTER(_vp)]),
+    "srt_comm_available": (_i, []),
+    "srt_comm_set_gather_planes": (_i, [_vp, _u32]),
+    "srt_comm_last_gather_ms": (_i, [_vp, C.POINTER(_f)]),
     "srt_comm_destroy": (None, [_vp]),
     "srt_comm_last_error": (C.c_char_p, [_vp]),
     "srt_comm_world": (_u32, [_vp]),

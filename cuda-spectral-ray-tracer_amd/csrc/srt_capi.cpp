@@ -28,6 +28,7 @@ struct srt_ctx {
     uint64_t seed = SRT_DEFAULT_SEED;
     uint32_t n_lanes = 0;
     uint32_t rank = 0, world = 1;
+    uint32_t gather_planes = 3;          // planes of the exchange unit: 3 = the quantised framebuffer, 9 = + the parity planes
     // last chunk
     uint32_t last_w = 0, last_h = 0, last_offx = 0, last_offy = 0;
     uint32_t tiles_x = 0, tiles_y = 0, n_tiles = 0, tiles_local = 0, tiles_padded = 0;
@@ -102,6 +103,7 @@ void fill_params(const srt_ctx *c, RenderParams &p) {
     p.rank = c->rank; p.world = c->world;
     p.rng = c->d_rng; p.n_lanes = c->n_lanes;
     p.tile_out = c->d_tiles; p.counters = c->d_counters;
+    p.tile_group_stride = c->tiles_padded * (uint32_t)(kGroupPlanes * kTileLanes);
 }
 
 }  // namespace
@@ -219,6 +221,12 @@ int srt_set_partition(srt_ctx *c, uint32_t rank, uint32_t world) {
     return SRT_OK;
 }
 
+int srt_set_gather_planes(srt_ctx *c, uint32_t planes) {
+    if (!c || (planes != 3 && planes != 9)) return fail(c, SRT_ERR_INVALID, "srt_set_gather_planes: planes must be 3 or 9");
+    c->gather_planes = planes;
+    return SRT_OK;
+}
+
 int srt_render_chunk(srt_ctx *c, uint32_t width, uint32_t height, uint32_t offx, uint32_t offy, void *stream) {
     if (!c) return fail(c, SRT_ERR_INVALID, "srt_render_chunk: null ctx");
     // reference: "Device parameters were not initialized, render aborted" (rendering.cu:247-250)
@@ -306,7 +314,7 @@ int srt_synchronize(srt_ctx *c) {
 int srt_tile_buffer(srt_ctx *c, void **dev_ptr, size_t *n_floats, uint32_t *tiles_local, uint32_t *tiles_padded) {
     if (!c || !c->d_tiles) return fail(c, SRT_ERR_INVALID, "srt_tile_buffer: nothing rendered yet");
     if (dev_ptr) *dev_ptr = c->d_tiles;
-    if (n_floats) *n_floats = (size_t)c->tiles_padded * kTilePlanes * kTileLanes;
+    if (n_floats) *n_floats = (size_t)c->tiles_padded * c->gather_planes * kTileLanes;      // the exchange unit: the first 1 or 3 plane groups
     if (tiles_local) *tiles_local = c->tiles_local;
     if (tiles_padded) *tiles_padded = c->tiles_padded;
     return SRT_OK;
@@ -315,20 +323,23 @@ int srt_tile_buffer(srt_ctx *c, void **dev_ptr, size_t *n_floats, uint32_t *tile
 int srt_copy_tile_buffer(srt_ctx *c, void *dst_dev, void *stream) {
     if (!c || !c->d_tiles || !dst_dev) return fail(c, SRT_ERR_INVALID, "srt_copy_tile_buffer: nothing rendered yet / null destination");
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipMemcpyAsync(dst_dev, c->d_tiles, (size_t)c->tiles_padded * kTilePlanes * kTileLanes * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    HIP_TRY(c, hipMemcpyAsync(dst_dev, c->d_tiles, (size_t)c->tiles_padded * c->gather_planes * kTileLanes * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return SRT_OK;
 }
 
 int srt_scatter_tiles(srt_ctx *c, const void *dev_gathered, void *stream) {
     if (!c || !c->d_fb || !c->d_tiles) return fail(c, SRT_ERR_INVALID, "srt_scatter_tiles: nothing rendered yet");
+    uint32_t groups = c->gather_planes / (uint32_t)kGroupPlanes;
     if (!dev_gathered) {
         if (c->world != 1) return fail(c, SRT_ERR_INVALID, "srt_scatter_tiles: a gathered buffer is required when world > 1");
         dev_gathered = c->d_tiles;
+        groups = (uint32_t)kTileGroups;      // the context's own tile buffer always holds all nine planes
     }
     HIP_TRY(c, hipSetDevice(c->device));
     ScatterParams sp;
     memset(&sp, 0, sizeof(sp));
     sp.gathered = (const float *)dev_gathered;
+    sp.groups = groups;
     for (int p = 0; p < kTilePlanes; p++) sp.fb[p] = c->d_fb + (size_t)p * c->n_lanes;
     sp.width = c->last_w; sp.height = c->last_h;
     sp.tx = c->tx; sp.ty = c->ty; sp.bx = c->bx; sp.by = c->by;
@@ -496,10 +507,10 @@ int srt_calibrate(srt_ctx *c, int kind, uint32_t waves_per_simd, uint32_t iters,
     (void)hipFree(d_cyc);
     if (d_sink) (void)hipFree(d_sink);
     if (e != hipSuccess) return hip_fail(c, e, "srt_calibrate");
-    double sum = 0, mx = 0;
-    for (unsigned long long v : h) { sum += (double)v; mx = std::max(mx, (double)v); }
+    double sum = 0, mx = 0, mn = 1e300;
+    for (unsigned long long v : h) { sum += (double)v; mx = std::max(mx, (double)v); mn = std::min(mn, (double)v); }
     memset(out, 0, sizeof(*out));
-    out->wave_cycles_mean = sum / n_waves; out->wave_cycles_max = mx; out->wall_ms = ms;
+    out->wave_cycles_mean = sum / n_waves; out->wave_cycles_max = mx; out->wave_cycles_min = mn; out->wall_ms = ms;
     out->instr_per_wave = (uint64_t)iters * 32u;
     out->n_waves = n_waves; out->n_cu = n_blocks; out->waves_per_simd = waves_per_simd;
     return SRT_OK;

@@ -15,6 +15,7 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
@@ -30,6 +31,7 @@ namespace {
 
 struct RcclApi {
     void *handle = nullptr;
+    bool preloaded = false;            // the process had an RCCL mapped already (e.g. PyTorch's) and we use that one
     decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
     decltype(&ncclCommInitRank) CommInitRank = nullptr;
     decltype(&ncclCommInitAll) CommInitAll = nullptr;
@@ -45,12 +47,27 @@ RcclApi &rccl() {
     static RcclApi api;
     static std::once_flag once;
     std::call_once(once, [] {
+        // A host process may already carry an RCCL (PyTorch maps its own copy): use THAT one -- two copies of the library in
+        // one process would each keep their own bootstrap state and device-side buffers.  RTLD_NOLOAD only succeeds for an
+        // image that is already mapped.  Otherwise load the system library.  SRT_RCCL_LIB names one explicit library instead
+        // (no fall-backs: also how the CPU suite tests the "RCCL missing" path).
         const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-        for (const char *n : names) {
-            api.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
-            if (api.handle) break;
+        std::string first_error;
+        auto try_open = [&](const char *n, int flags) {
+            if (api.handle) return;
+            (void)dlerror();
+            api.handle = dlopen(n, flags);
+            if (!api.handle && first_error.empty()) { const char *e = dlerror(); first_error = e ? e : (std::string(n) + " not found"); }
+        };
+        if (const char *forced = getenv("SRT_RCCL_LIB")) {
+            try_open(forced, RTLD_NOW | RTLD_LOCAL);
+        } else {
+            for (const char *n : names) try_open(n, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
+            api.preloaded = api.handle != nullptr;
+            first_error.clear();      // "not already mapped" is not an error
+            for (const char *n : names) try_open(n, RTLD_NOW | RTLD_LOCAL);
         }
-        if (!api.handle) { api.error = std::string("cannot load RCCL: ") + (dlerror() ? dlerror() : "librccl.so.1 not found"); return; }
+        if (!api.handle) { api.error = "cannot load RCCL: " + (first_error.empty() ? std::string("librccl.so.1 not found") : first_error); return; }
         bool ok = true;
         auto sym = [&](const char *name) { void *p = dlsym(api.handle, name); if (!p) { ok = false; api.error = std::string("RCCL symbol missing: ") + name; } return p; };
         api.GetUniqueId = (decltype(api.GetUniqueId))sym("ncclGetUniqueId");
@@ -78,6 +95,9 @@ struct srt_comm {
     int root_local = -1;               // index of global rank 0 among the local contexts, -1 if it lives elsewhere
     float *d_gathered = nullptr;       // on rank 0's device: world * tiles_padded * 9 * 64 floats, rank-major
     size_t gathered_capacity = 0;
+    uint32_t gather_planes = 3;        // 3: the quantised framebuffer only (12 B / pixel); 9: + the parity planes
+    std::vector<hipEvent_t> ev_g0, ev_g1;   // per local context: around the gather (+ scatter on rank 0) of the last frame
+    bool gather_timed = false;
     std::string err;
 };
 
@@ -116,6 +136,21 @@ int srt_comm_unique_id(unsigned char id[SRT_COMM_ID_BYTES]) {
     return SRT_OK;
 }
 
+// SRT_OK when an RCCL is loadable in this process (cheap; lets a launcher agree on the exchange path BEFORE any rank enters
+// the collective ncclCommInitRank -- a rank that failed earlier would leave the others waiting in the bootstrap)
+int srt_comm_available(void) {
+    RcclApi &R = rccl();
+    if (!R.handle) return cfail(nullptr, SRT_ERR_UNSUPPORTED, "srt_comm_available: " + R.error);
+    return SRT_OK;
+}
+
+int srt_comm_set_gather_planes(srt_comm *c, uint32_t planes) {
+    if (!c || (planes != 3 && planes != 9)) return cfail(c, SRT_ERR_INVALID, "srt_comm_set_gather_planes: planes must be 3 or 9");
+    for (srt_ctx *x : c->ctx) { int rc = srt_set_gather_planes(x, planes); if (rc != SRT_OK) return cfail(c, rc, srt_last_error(x)); }
+    c->gather_planes = planes;
+    return SRT_OK;
+}
+
 int srt_comm_init_rank(srt_ctx *ctx, const unsigned char id[SRT_COMM_ID_BYTES], uint32_t rank, uint32_t world, srt_comm **out) {
     if (!ctx || !id || !out || world == 0 || rank >= world) return cfail(nullptr, SRT_ERR_INVALID, "srt_comm_init_rank: bad argument");
     *out = nullptr;
@@ -124,7 +159,7 @@ int srt_comm_init_rank(srt_ctx *ctx, const unsigned char id[SRT_COMM_ID_BYTES], 
     COMM_HIP(nullptr, hipSetDevice(device_of(ctx)));
     srt_comm *c = new srt_comm();
     c->world = world; c->ctx = {ctx}; c->rank = {rank}; c->owns_ctx = false; c->root_local = rank == 0 ? 0 : -1;
-    c->nccl.assign(1, nullptr); c->stream.assign(1, nullptr);
+    c->nccl.assign(1, nullptr); c->stream.assign(1, nullptr); c->ev_g0.assign(1, nullptr); c->ev_g1.assign(1, nullptr);
     ncclUniqueId u;
     memcpy(u.internal, id, NCCL_UNIQUE_ID_BYTES);
     ncclResult_t r = R.CommInitRank(&c->nccl[0], (int)world, u, (int)rank);
@@ -132,6 +167,8 @@ int srt_comm_init_rank(srt_ctx *ctx, const unsigned char id[SRT_COMM_ID_BYTES], 
     hipError_t e = hipStreamCreateWithFlags(&c->stream[0], hipStreamNonBlocking);
     if (e != hipSuccess) { int rc = cfail(nullptr, SRT_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e)); srt_comm_destroy(c); return rc; }
     int rc = srt_set_partition(ctx, rank, world);
+    if (rc == SRT_OK) rc = srt_set_gather_planes(ctx, c->gather_planes);
+    if (rc == SRT_OK && (hipEventCreate(&c->ev_g0[0]) != hipSuccess || hipEventCreate(&c->ev_g1[0]) != hipSuccess)) rc = cfail(nullptr, SRT_ERR_HIP, "srt_comm_init_rank: hipEventCreate failed");
     if (rc != SRT_OK) { srt_comm_destroy(c); return rc; }
     *out = c;
     return SRT_OK;
@@ -148,10 +185,13 @@ int srt_comm_init_all(const int *devices, int n, srt_comm **out) {
     srt_comm *c = new srt_comm();
     c->world = (uint32_t)n; c->owns_ctx = true; c->root_local = 0;
     c->ctx.assign(n, nullptr); c->rank.resize(n); c->nccl.assign(n, nullptr); c->stream.assign(n, nullptr);
+    c->ev_g0.assign(n, nullptr); c->ev_g1.assign(n, nullptr);
     for (int i = 0; i < n; i++) {
         c->rank[i] = (uint32_t)i;
         int rc = srt_create(devices[i], &c->ctx[i]);
         if (rc == SRT_OK) rc = srt_set_partition(c->ctx[i], (uint32_t)i, (uint32_t)n);
+        if (rc == SRT_OK) rc = srt_set_gather_planes(c->ctx[i], c->gather_planes);
+        if (rc == SRT_OK && (hipEventCreate(&c->ev_g0[i]) != hipSuccess || hipEventCreate(&c->ev_g1[i]) != hipSuccess)) rc = cfail(nullptr, SRT_ERR_HIP, "srt_comm_init_all: hipEventCreate failed");
         if (rc == SRT_OK && hipStreamCreateWithFlags(&c->stream[i], hipStreamNonBlocking) != hipSuccess) rc = cfail(nullptr, SRT_ERR_HIP, "srt_comm_init_all: hipStreamCreate failed");
         if (rc != SRT_OK) { srt_comm_destroy(c); return rc; }
     }
@@ -168,6 +208,8 @@ void srt_comm_destroy(srt_comm *c) {
         if (c->ctx[i]) { (void)hipSetDevice(device_of(c->ctx[i])); (void)hipDeviceSynchronize(); }
         if (c->nccl[i] && R.handle) (void)R.CommDestroy(c->nccl[i]);
         if (c->stream[i]) (void)hipStreamDestroy(c->stream[i]);
+        if (i < c->ev_g0.size() && c->ev_g0[i]) (void)hipEventDestroy(c->ev_g0[i]);
+        if (i < c->ev_g1.size() && c->ev_g1[i]) (void)hipEventDestroy(c->ev_g1[i]);
     }
     if (c->d_gathered && c->root_local >= 0) { (void)hipSetDevice(device_of(c->ctx[c->root_local])); (void)hipFree(c->d_gathered); }
     if (c->owns_ctx) for (srt_ctx *x : c->ctx) if (x) srt_destroy(x);
@@ -211,7 +253,7 @@ int srt_render_frame_multi(srt_comm *c, uint32_t width, uint32_t height, uint32_
         int rc = srt_render_chunk(c->ctx[i], width, height, offx, offy, c->stream[i]);
         if (rc != SRT_OK) return cfail(c, rc, srt_last_error(c->ctx[i]));
     }
-    // every rank's buffer has the same size: tiles_padded * 9 * 64 floats
+    // every rank's exchange unit has the same size: tiles_padded * gather_planes * 64 floats (the first plane groups of its buffer)
     void *tiles0 = nullptr; size_t n_floats = 0; uint32_t tl = 0, tp = 0;
     int rc = srt_tile_buffer(c->ctx[0], &tiles0, &n_floats, &tl, &tp);
     if (rc != SRT_OK) return cfail(c, rc, srt_last_error(c->ctx[0]));
@@ -226,6 +268,10 @@ int srt_render_frame_multi(srt_comm *c, uint32_t width, uint32_t height, uint32_
         COMM_HIP(c, hipMalloc((void **)&c->d_gathered, (size_t)c->world * n_floats * sizeof(float)));
         c->gathered_capacity = (size_t)c->world * n_floats;
     }
+    for (size_t i = 0; i < n_local; i++) {
+        COMM_HIP(c, hipSetDevice(device_of(c->ctx[i])));
+        COMM_HIP(c, hipEventRecord(c->ev_g0[i], c->stream[i]));
+    }
     COMM_NCCL(c, R.GroupStart());
     for (size_t i = 0; i < n_local; i++) {
         void *tiles = nullptr; size_t nf = 0;
@@ -238,6 +284,27 @@ int srt_render_frame_multi(srt_comm *c, uint32_t width, uint32_t height, uint32_
     if (c->root_local >= 0) {
         rc = srt_scatter_tiles(c->ctx[c->root_local], c->d_gathered, c->stream[c->root_local]);
         if (rc != SRT_OK) return cfail(c, rc, srt_last_error(c->ctx[c->root_local]));
+    }
+    for (size_t i = 0; i < n_local; i++) {
+        COMM_HIP(c, hipSetDevice(device_of(c->ctx[i])));
+        COMM_HIP(c, hipEventRecord(c->ev_g1[i], c->stream[i]));
+    }
+    c->gather_timed = true;
+    return SRT_OK;
+}
+
+// time the local ranks spent between the end of their render kernel and the end of the exchange of the last frame (the gather,
+// plus the scatter on rank 0; includes waiting for the slowest rank): max over the local contexts, ms.  0 for a 1-rank world.
+int srt_comm_last_gather_ms(srt_comm *c, float *ms) {
+    if (!c || !ms) return cfail(c, SRT_ERR_INVALID, "srt_comm_last_gather_ms: null argument");
+    *ms = 0.f;
+    if (c->world == 1 || !c->gather_timed) return SRT_OK;
+    for (size_t i = 0; i < c->ctx.size(); i++) {
+        float t = 0.f;
+        COMM_HIP(c, hipSetDevice(device_of(c->ctx[i])));
+        COMM_HIP(c, hipEventSynchronize(c->ev_g1[i]));
+        COMM_HIP(c, hipEventElapsedTime(&t, c->ev_g0[i], c->ev_g1[i]));
+        *ms = t > *ms ? t : *ms;
     }
     return SRT_OK;
 }

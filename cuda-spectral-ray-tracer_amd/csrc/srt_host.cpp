@@ -13,6 +13,7 @@
 #include <mutex>
 
 #include "srt_cie_data.h"
+#include "srt_color_consts.h"
 #include "srt_powf.h"
 
 namespace srt {
@@ -354,7 +355,9 @@ int flatten_scene(const srt_scene &s, FlatScene &out) {
     const size_t n_tris = s.raw.size(), n_mats = s.mats.size();
     for (size_t k = 0; k < n_tris; k++)
         if (s.raw[k].mat_index >= n_mats) { set_global_error("upload: triangle references a missing material"); return SRT_ERR_INVALID; }
-    if (n_mats >= (1u << 23)) { set_global_error("upload: too many materials"); return SRT_ERR_INVALID; }
+    // the kernel addresses the spectrum tables with 32-bit byte offsets ((n_mats + 1) tables of 768 B, the background last) and
+    // forms them with a 24-bit multiply: both bounds, like the 48-byte shade and 96-byte fringe products below
+    if ((uint64_t)(n_mats + 1) * 768ull >= (1ull << 32) || n_mats >= (1u << 23)) { set_global_error("upload: too many materials (limit 5 592 403)"); return SRT_ERR_INVALID; }
     if (n_tris >= (1u << 24)) { set_global_error("upload: too many triangles (record offsets are formed with 24-bit multiplies)"); return SRT_ERR_INVALID; }
 
     // triangles: a = {n, D}, b = {v0[w], v0[h], v1[w], v1[h]}, c = {v2[w], v2[h], flags, 0}
@@ -486,6 +489,20 @@ static void cie_init() {
 #undef ROW
     });
 }
+}  // namespace srt
+// The constant tables this build computes with, for the pinning test (tests/test_ref_tables.py): rows {x_bar, y_bar, z_bar,
+// normalised D65} of utils/cie_const.cu:12-122 and the d65_XYZ_to_sRGB matrix of utils/color_const.cu:17-19.
+extern "C" int srt_color_tables(float cmf[SRT_N_CIE_SAMPLES * 4], float xyz_to_srgb[9]) {
+    if (!cmf || !xyz_to_srgb) { srt::set_global_error("srt_color_tables: null argument"); return SRT_ERR_INVALID; }
+    float rows[96 * 4];
+    srt::cmf_rows(rows);
+    memcpy(cmf, rows, sizeof(float) * SRT_N_CIE_SAMPLES * 4);
+    const float m[9] = {SRT_XYZ2RGB_00, SRT_XYZ2RGB_01, SRT_XYZ2RGB_02, SRT_XYZ2RGB_10, SRT_XYZ2RGB_11, SRT_XYZ2RGB_12,
+                        SRT_XYZ2RGB_20, SRT_XYZ2RGB_21, SRT_XYZ2RGB_22};
+    memcpy(xyz_to_srgb, m, sizeof(m));
+    return SRT_OK;
+}
+namespace srt {
 void cmf_rows(float *rows) {
     cie_init();
     memset(rows, 0, 96 * 4 * sizeof(float));

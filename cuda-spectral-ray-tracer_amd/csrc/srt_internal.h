@@ -7,6 +7,8 @@
 namespace srt {
 
 constexpr int kTilePlanes = 9;      // quantised rgb | unquantised sRGB | XYZ sums
+constexpr int kTileGroups = 3;      // ... in three groups of three planes; group 0 (the quantised framebuffer) is what the multi-GPU gather moves
+constexpr int kGroupPlanes = 3;
 constexpr int kTileLanes = 64;      // one wave = one 8x8 pixel tile
 constexpr int kCounters = 24;       // rays, node_visits, tri_tests, box_tests, utilisation counters (instrumented build)
 
@@ -49,12 +51,14 @@ struct RenderParams {
     // state / outputs
     uint32_t *rng;                        // SoA: 6 planes of n_lanes words, indexed by the block-linear idx
     uint32_t n_lanes;                     // tx*ty*bx*by
-    float *tile_out;                      // [local tile][plane][lane]
+    float *tile_out;                      // [group][local tile (tiles_padded of them)][plane of the group][lane]
+    uint32_t tile_group_stride;           // floats between two groups = tiles_padded * 3 * 64
     unsigned long long *counters;
 };
 
 struct ScatterParams {
-    const float *gathered;     // [rank][tiles_padded][plane][lane]
+    const float *gathered;     // [rank][group (groups of them)][tiles_padded][plane of the group][lane]
+    uint32_t groups;           // 1: only the quantised framebuffer was gathered (12 B / pixel); 3: the parity planes too
     float *fb[9];              // block-linear planes: r g b | lin r g b | X Y Z
     uint32_t width, height;
     uint32_t tx, ty, bx, by;

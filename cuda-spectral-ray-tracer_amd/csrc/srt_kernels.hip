@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <stdlib.h>
 
+#include "srt_color_consts.h"
 #include "srt_device.h"
 #include "srt_internal.h"
 
@@ -38,6 +39,7 @@ struct LdsUniforms {
     uint32_t n_rows;          // queue length in rows of 64 pixel slots (= tiles_local unless expensive tiles were split)
     uint32_t lane_limit;
     uint32_t rng[2], tile_out[2], tile_order[2], tile_cost[2], pixel_counter[2];
+    uint32_t tile_group_stride;
 };
 static_assert(sizeof(LdsUniforms) <= kLdsUniF4 * 16, "uniform block too large");
 typedef __attribute__((address_space(3))) LdsUniforms lds_uniforms;
@@ -166,6 +168,7 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
         U->tiles_x = P.tiles_x; U->n_tiles = P.n_tiles; U->rank = P.rank; U->world = P.world; U->spp = P.spp; U->n_lanes = P.n_lanes;
         split_ptr(P.rng, U->rng); split_ptr(P.tile_out, U->tile_out); split_ptr(P.tile_order, U->tile_order);
         split_ptr(P.tile_cost, U->tile_cost); split_ptr(P.pixel_counter, U->pixel_counter);
+        U->tile_group_stride = P.tile_group_stride;
     }
     for (uint32_t k = threadIdx.x; k < kLdsCmfF4; k += blockDim.x) s_cmf[k] = P.cmf[k];
     for (uint32_t k = threadIdx.x; k < nc; k += blockDim.x) {
@@ -202,7 +205,7 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
     // ---- lane state ---------------------------------------------------------------------------------------
     bool dead = false, have_path = false, have_pixel = false;
     uint32_t idx = 0;                       // block-linear index of the current pixel (RNG / framebuffer slot)
-    uint32_t out_slot = 0;                  // tile_local * 576 + lane_in_tile
+    uint32_t out_slot = 0;                  // tile_local * 192 + lane_in_tile (slot inside a plane group of the tile buffer)
     uint32_t pixel_ij = 0;                  // chunk-relative column | row << 16 (both are 16-bit quantities, Q17)
     Rng rs; rs.d = rs.v0 = rs.v1 = rs.v2 = rs.v3 = rs.v4 = 0u;
     V3 acc = mk(0.f, 0.f, 0.f);             // pixel_color (rendering.cu:212)
@@ -376,16 +379,19 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
                     // pixel_color / float(spp) -> (1/spp) * v ; XYZ_to_sRGB (color.cu:35-41, vec3.cuh:80-91)
                     const float inv_spp = 1.0f / (float)spp;
                     const V3 c = inv_spp * acc;
-                    const float r_lin = (3.2404542f * c.x) + (-1.5371385f * c.y) + (-0.4985314f * c.z);
-                    const float g_lin = (-0.9692660f * c.x) + (1.8760108f * c.y) + (0.0415560f * c.z);
-                    const float b_lin = (0.0556434f * c.x) + (-0.2040259f * c.y) + (1.0572252f * c.z);
+                    const float r_lin = (SRT_XYZ2RGB_00 * c.x) + (SRT_XYZ2RGB_01 * c.y) + (SRT_XYZ2RGB_02 * c.z);
+                    const float g_lin = (SRT_XYZ2RGB_10 * c.x) + (SRT_XYZ2RGB_11 * c.y) + (SRT_XYZ2RGB_12 * c.z);
+                    const float b_lin = (SRT_XYZ2RGB_20 * c.x) + (SRT_XYZ2RGB_21 * c.y) + (SRT_XYZ2RGB_22 * c.z);
                     const float r = correct_channel(r_lin), g = correct_channel(g_lin), b = correct_channel(b_lin);
+                    // three groups of three planes: the quantised framebuffer (what a multi-GPU gather moves), then the two
+                    // parity groups (unquantised sRGB, XYZ sums)
                     float *o = join_ptr<float>(U->tile_out[0], U->tile_out[1]) + out_slot;
+                    const size_t gs = U->tile_group_stride;
                     o[0 * kTileLanes] = (float)(int)(r * 255.99f);      // expand_sRGB (color.cu:43-49, Q15)
                     o[1 * kTileLanes] = (float)(int)(g * 255.99f);
                     o[2 * kTileLanes] = (float)(int)(b * 255.99f);
-                    o[3 * kTileLanes] = r; o[4 * kTileLanes] = g; o[5 * kTileLanes] = b;
-                    o[6 * kTileLanes] = acc.x; o[7 * kTileLanes] = acc.y; o[8 * kTileLanes] = acc.z;
+                    o[gs + 0 * kTileLanes] = r; o[gs + 1 * kTileLanes] = g; o[gs + 2 * kTileLanes] = b;
+                    o[2 * gs + 0 * kTileLanes] = acc.x; o[2 * gs + 1 * kTileLanes] = acc.y; o[2 * gs + 2 * kTileLanes] = acc.z;
                     have_pixel = false;
                 }
                 // fetch the next pixel of this rank's queue (wave-aggregated atomic); skip slots outside the chunk
@@ -427,7 +433,7 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
                         // pixels outside the chunk (or the reference grid) never touch RNG or output (rendering.cu:205)
                         if ((tile < U->n_tiles) && (lt < U->lane_limit) && (i < U->width) && (j < U->height) && (i / gtx < gbx) && (j / gty < U->by)) {
                             idx = block_linear_idx(i, j, gtx, gty, gbx);
-                            out_slot = tile_local * (uint32_t)(kTilePlanes * kTileLanes) + lt;
+                            out_slot = tile_local * (uint32_t)(kGroupPlanes * kTileLanes) + lt;
                             pixel_ij = i | (j << 16);
                             {
                                 const uint32_t *rng = join_ptr<const uint32_t>(U->rng[0], U->rng[1]);      // rendering.cu:209
@@ -716,9 +722,11 @@ __global__ __launch_bounds__(64) void scatter_tiles_kernel(const ScatterParams P
     if (i >= P.width || j >= P.height || i / P.tx >= P.bx || j / P.ty >= P.by) return;
     const uint32_t idx = block_linear_idx(i, j, P.tx, P.ty, P.bx);
     const uint32_t rank = tile % P.world, local = tile / P.world;
-    const float *src = P.gathered + ((size_t)rank * P.tiles_padded + local) * (kTilePlanes * kTileLanes) + lane;
+    for (uint32_t g = 0; g < P.groups; g++) {
+        const float *src = P.gathered + (((size_t)rank * P.groups + g) * P.tiles_padded + local) * (kGroupPlanes * kTileLanes) + lane;
 #pragma unroll
-    for (int p = 0; p < kTilePlanes; p++) P.fb[p][idx] = src[p * kTileLanes];
+        for (int p = 0; p < kGroupPlanes; p++) P.fb[g * kGroupPlanes + p][idx] = src[p * kTileLanes];
+    }
 }
 
 // render_manager::update_fb's un-swizzle (render_manager.cuh:68-142), one thread per block-linear index.

@@ -66,6 +66,10 @@ class Renderer:
     def synchronize(self):
         self._ck(B.lib().srt_synchronize(self._h))
 
+    def set_gather_planes(self, planes):
+        """3 (default): the exchange unit is the quantised framebuffer; 9: + the parity planes (unquantised sRGB, XYZ sums)"""
+        self._ck(B.lib().srt_set_gather_planes(self._h, planes))
+
     def tile_buffer(self):
         ptr, n, tl, tp = C.c_void_p(), C.c_size_t(), C.c_uint32(), C.c_uint32()
         self._ck(B.lib().srt_tile_buffer(self._h, C.byref(ptr), C.byref(n), C.byref(tl), C.byref(tp)))
@@ -122,16 +126,23 @@ class Renderer:
         return ms.value
 
     def calibrate(self, kind, waves_per_simd=4, iters=20000):
-        """Issue-rate microkernel (csrc/srt_calib.hip).  Returns per-SIMD instructions per cycle and the chip-wide rate."""
+        """Issue-rate microkernel (csrc/srt_calib.hip): one workgroup of waves_per_simd * 256 threads on every CU.
+
+        The SIMD's arbiter prefers older waves, so with four resident waves two of them run at their single-wave speed and
+        finish at about half of the launch; the rate a SIMD sustains is therefore the instructions of ALL its waves over the
+        cycles of the LAST one (wave_cycles_max, = wall x clock), not over the mean wave life -- the mean-based figure of round 2
+        (0.585 / cycle) belongs to no SIMD.  `instr_per_cycle_per_simd` is the max-based rate; min / mean / max are all returned."""
         cal = B.Calibration()
         self._ck(B.lib().srt_calibrate(self._h, kind, waves_per_simd, iters, C.byref(cal)))
         n_simd = cal.n_cu * 4
         total = cal.instr_per_wave * cal.n_waves
-        return dict(kind=kind, waves_per_simd=cal.waves_per_simd, n_cu=cal.n_cu, wave_cycles_mean=cal.wave_cycles_mean,
-                    wave_cycles_max=cal.wave_cycles_max, wall_ms=cal.wall_ms, instr_per_wave=cal.instr_per_wave,
-                    instr_per_cycle_per_simd=cal.instr_per_wave * cal.waves_per_simd / cal.wave_cycles_mean,
-                    instr_per_s=total / (cal.wall_ms * 1e-3), clock_ghz=cal.wave_cycles_max / (cal.wall_ms * 1e-3) / 1e9,
-                    n_simd=n_simd)
+        clock_ghz = cal.wave_cycles_max / (cal.wall_ms * 1e-3) / 1e9        # the slowest wave spans the launch: its cycles / wall
+        return dict(kind=kind, waves_per_simd=cal.waves_per_simd, n_cu=cal.n_cu, wave_cycles_min=cal.wave_cycles_min,
+                    wave_cycles_mean=cal.wave_cycles_mean, wave_cycles_max=cal.wave_cycles_max, wall_ms=cal.wall_ms,
+                    instr_per_wave=cal.instr_per_wave,
+                    instr_per_cycle_per_simd=cal.instr_per_wave * cal.waves_per_simd / cal.wave_cycles_max,
+                    instr_per_cycle_per_simd_mean_wave=cal.instr_per_wave * cal.waves_per_simd / cal.wave_cycles_mean,
+                    instr_per_s=total / (cal.wall_ms * 1e-3), clock_ghz=clock_ghz, n_simd=n_simd)
 
     def trace_rays(self, rays):
         rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
@@ -154,6 +165,11 @@ class Comm:
     def __init__(self, handle, renderers, owns):
         self._h, self.renderers, self._owns = handle, renderers, owns
         self.world = B.lib().srt_comm_world(handle)
+
+    @staticmethod
+    def available():
+        """True when an RCCL can be loaded in this process (no collective involved)"""
+        return B.lib().srt_comm_available() == 0
 
     @staticmethod
     def unique_id():
@@ -214,6 +230,14 @@ class Comm:
         self._ck(B.lib().srt_comm_init_device_params(self._h, tx, ty, bx, by, chunk_w, chunk_h, spp, bounce_limit, seed))
         for r in self.renderers:
             r.geom = dict(tx=tx, ty=ty, bx=bx, by=by, chunk_w=chunk_w, chunk_h=chunk_h, n_lanes=tx * ty * bx * by)
+
+    def set_gather_planes(self, planes):
+        self._ck(B.lib().srt_comm_set_gather_planes(self._h, planes))
+
+    def last_gather_ms(self):
+        ms = C.c_float()
+        self._ck(B.lib().srt_comm_last_gather_ms(self._h, C.byref(ms)))
+        return ms.value
 
     def render_frame(self, width, height, offx=0, offy=0):
         self._ck(B.lib().srt_render_frame_multi(self._h, width, height, offx, offy))

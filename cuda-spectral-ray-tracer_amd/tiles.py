@@ -10,7 +10,9 @@ import torch
 import torch.distributed as dist
 
 TILE = 8
-PLANES = 9
+PLANES = 9          # quantised r,g,b | unquantised sRGB r,g,b | XYZ sums
+GROUP_PLANES = 3    # ... in three groups of three; a rank's tile buffer is [group][tile][plane of the group][lane]
+GROUPS = 3          # the gather moves the first group (the quantised framebuffer, 12 B / pixel) or all three (parity tests)
 LANES = 64
 
 
@@ -30,8 +32,8 @@ def local_tile_ids(n_tiles, rank, world):
 
 
 def gather_tiles(local, rank, world, group=None, dst=0):
-    """local: [tiles_padded, PLANES, LANES] float32 tensor (same shape on every rank).
-    Returns [world, tiles_padded, PLANES, LANES] on rank `dst`, None elsewhere.  One collective."""
+    """local: [groups, tiles_padded, GROUP_PLANES, LANES] float32 tensor (same shape on every rank; groups = 1 or 3).
+    Returns [world, groups, tiles_padded, GROUP_PLANES, LANES] on rank `dst`, None elsewhere.  One collective."""
     if world == 1:
         return local.unsqueeze(0)
     if rank == dst:
@@ -49,18 +51,20 @@ def block_linear_index(i, j, tx, ty, bx):
 
 
 def scatter_tiles_torch(gathered, width, height, tx, ty, bx, by, world):
-    """Pure-torch scatter of gathered tiles into PLANES block-linear planes (used by the CPU/gloo tests; the GPU
-    path uses srt_scatter_tiles).  gathered: [world, tiles_padded, PLANES, LANES]."""
+    """Pure-torch scatter of gathered tiles into block-linear planes (used by the CPU/gloo tests; the GPU path uses
+    srt_scatter_tiles).  gathered: [world, groups, tiles_padded, GROUP_PLANES, LANES]; returns [groups * 3, n_lanes]."""
     g = tile_geometry(width, height, tx, ty, bx, by, world)
     n_lanes = tx * ty * bx * by
-    fb = torch.zeros((PLANES, n_lanes), dtype=gathered.dtype, device=gathered.device)
+    groups = gathered.shape[1]
+    fb = torch.zeros((groups * GROUP_PLANES, n_lanes), dtype=gathered.dtype, device=gathered.device)
     t = torch.arange(g["n_tiles"], device=gathered.device)
     lane = torch.arange(LANES, device=gathered.device)
     i = (t % g["tiles_x"])[:, None] * TILE + (lane % TILE)[None, :]
     j = (t // g["tiles_x"])[:, None] * TILE + (lane // TILE)[None, :]
     ok = (i < g["cover_w"]) & (j < g["cover_h"])
     idx = block_linear_index(i, j, tx, ty, bx)
-    src = gathered[t % world, t // world]            # [n_tiles, PLANES, LANES]
-    for p in range(PLANES):
-        fb[p][idx[ok]] = src[:, p, :][ok]
+    for grp in range(groups):
+        src = gathered[t % world, grp, t // world]            # [n_tiles, GROUP_PLANES, LANES]
+        for p in range(GROUP_PLANES):
+            fb[grp * GROUP_PLANES + p][idx[ok]] = src[:, p, :][ok]
     return fb

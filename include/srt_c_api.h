@@ -135,6 +135,11 @@ SRT_API int srt_bake_sigmoid_spectrum(const float coeffs[3], float scale, int ti
  * srt_bake_sigmoid_spectrum expects.  Not pinned against the author's table. */
 SRT_API int srt_fit_sigmoid_coeffs(const float rgb[3], float coeffs[3]);
 /* host srgb_to_illuminance_spectrum for the background (rendering/rendering.cu:324), grey colours only. */
+/* The constant tables the path computes with: cmf = 95 rows {x_bar, y_bar, z_bar, normalised D65} (cie_x / cie_y / cie_z /
+ * normalized_cie_d65, utils/cie_const.cu:12-122, the host copies the reference uploads into dev_cie_* with
+ * cudaMemcpyToSymbol) and the row-major d65_XYZ_to_sRGB matrix (utils/color_const.cu:17-19).  tests/test_ref_tables.py
+ * compares them bit for bit with the reference's own arrays compiled from its sources (oracle/Makefile, target `ref`). */
+SRT_API int srt_color_tables(float cmf[SRT_N_CIE_SAMPLES * 4], float xyz_to_srgb[9]);
 SRT_API int srt_background_spectrum(const float rgb[3], float out[SRT_N_CIE_SAMPLES]);
 
 /* BVH: `mode` SRT_BVH_REFERENCE reproduces create_bvh_kernel (fresh XORWOW(seed), bvh/bvh.cu:206-346);
@@ -177,16 +182,20 @@ SRT_API int srt_set_partition(srt_ctx *ctx, uint32_t rank, uint32_t world);
 SRT_API int srt_render_chunk(srt_ctx *ctx, uint32_t width, uint32_t height, uint32_t offx, uint32_t offy, void *stream);
 SRT_API int srt_synchronize(srt_ctx *ctx);
 
-/* Compact tile buffer of this rank (device memory, for the RCCL gather): n_tiles_local * 9 * 64 floats,
- * [tile][plane][lane], planes = quantised r,g,b | unquantised sRGB r,g,b | XYZ sums.  tiles_padded is the
- * per-rank tile capacity ceil(n_tiles/world) so that every rank's buffer has the same size. */
+/* Compact tile buffer of this rank (device memory): three plane GROUPS of tiles_padded * 3 * 64 floats each,
+ * [group][tile][plane][lane] -- group 0 = quantised r,g,b (the reference's frame_buffer values, 12 B / pixel), group 1 =
+ * unquantised sRGB r,g,b, group 2 = XYZ sums (parity planes).  tiles_padded = ceil(n_tiles/world), so every rank's buffer has
+ * the same size.  The EXCHANGE UNIT of the multi-GPU gather is the first `planes` planes of it: 3 (default: what the
+ * reference's framebuffer holds) or 9 (srt_set_gather_planes: parity tests that compare the XYZ sums of a
+ * partitioned render).  srt_tile_buffer reports n_floats = tiles_padded * planes * 64. */
+SRT_API int srt_set_gather_planes(srt_ctx *ctx, uint32_t planes);
 SRT_API int srt_tile_buffer(srt_ctx *ctx, void **dev_ptr, size_t *n_floats, uint32_t *tiles_local, uint32_t *tiles_padded);
-/* Stream-ordered device-to-device copy of the tile buffer into caller-owned device memory (e.g. the tensor that is
+/* Stream-ordered device-to-device copy of the exchange unit into caller-owned device memory (e.g. the tensor that is
  * handed to the RCCL gather): n_floats as reported by srt_tile_buffer. */
 SRT_API int srt_copy_tile_buffer(srt_ctx *ctx, void *dst_dev, void *stream);
-/* Scatter gathered tile buffers (device pointer, world * tiles_padded * 9 * 64 floats, rank-major) into this
- * context's block-linear planar framebuffer (rendering.cu:146-148 layout).  With world == 1 pass the
- * context's own tile buffer (or NULL to use it). */
+/* Scatter gathered exchange units (device pointer, world * tiles_padded * planes * 64 floats, rank-major) into this
+ * context's block-linear planar framebuffer (rendering.cu:146-148 layout); with planes == 3 only the quantised planes are
+ * written.  With world == 1 pass NULL: the context's own tile buffer (all nine planes) is scattered. */
 SRT_API int srt_scatter_tiles(srt_ctx *ctx, const void *dev_gathered, void *stream);
 
 /* renderer::getDevFBr/g/b (rendering.cuh:87-97): device pointers to the block-linear planes (tx*bx*ty*by floats). */
@@ -230,6 +239,12 @@ SRT_API int srt_comm_init_all(const int *devices, int n, srt_comm **out);
  * to the other ranks by any channel; every rank then wraps its own context.  Sets the context's partition. */
 SRT_API int srt_comm_unique_id(unsigned char id[SRT_COMM_ID_BYTES]);
 SRT_API int srt_comm_init_rank(srt_ctx *ctx, const unsigned char id[SRT_COMM_ID_BYTES], uint32_t rank, uint32_t world, srt_comm **out);
+/* SRT_OK when an RCCL can be loaded in this process, SRT_ERR_UNSUPPORTED (with a message) otherwise.  Cheap and local: a
+ * launcher lets every rank call it and agrees on the exchange path BEFORE any rank enters the collective srt_comm_init_rank.
+ * An RCCL the host process already mapped (PyTorch's) is re-used; SRT_RCCL_LIB names an explicit library. */
+SRT_API int srt_comm_available(void);
+/* Planes the gather moves: 3 (default) = the quantised framebuffer, 12 B / pixel; 9 = + the parity planes (72 B / pixel). */
+SRT_API int srt_comm_set_gather_planes(srt_comm *comm, uint32_t planes);
 SRT_API void srt_comm_destroy(srt_comm *comm);                 /* destroys the contexts srt_comm_init_all created */
 SRT_API const char *srt_comm_last_error(const srt_comm *comm);
 SRT_API uint32_t srt_comm_world(const srt_comm *comm);
@@ -248,6 +263,9 @@ SRT_API int srt_render_frame_multi(srt_comm *comm, uint32_t width, uint32_t heig
 SRT_API int srt_comm_synchronize(srt_comm *comm);
 /* Closest-hit queries / paths of the last frame summed over the local ranks, and the slowest local render kernel. */
 SRT_API int srt_comm_stats(srt_comm *comm, uint64_t *rays, uint64_t *paths, float *max_kernel_ms);
+/* Time between the end of a local rank's render kernel and the end of the exchange of the last frame (gather + waiting for
+ * the slowest rank + the scatter on rank 0), max over the local ranks, ms; 0 in a 1-rank world. */
+SRT_API int srt_comm_last_gather_ms(srt_comm *comm, float *ms);
 
 /* Issue-rate calibration (no reference counterpart: measurement support for bench.py's roofline).  Runs microkernel
  * `kind` (csrc/srt_calib.hip: 0 v_add_f32, 1 v_pk_mul_f32, 2 v_fma_f32, 3 dependent v_add_f32 chain, 4 s_add_u32,
@@ -259,6 +277,8 @@ typedef struct {
     uint64_t instr_per_wave;                    /* instructions of the measured loop body per wave (loop control excluded) */
     uint32_t n_waves, n_cu, waves_per_simd;
     uint32_t reserved;
+    double wave_cycles_min;                     /* the SIMD arbitrates by age: with 4 resident waves the oldest finish first, so the
+                                                   rate of a SIMD is instructions / wave_cycles_max (or wall x clock), never / mean */
 } srt_calibration;
 SRT_API int srt_calibrate(srt_ctx *ctx, int kind, uint32_t waves_per_simd, uint32_t iters, srt_calibration *out);
 

@@ -16,7 +16,12 @@
  *     and the CUDA runtime headers).  Those headers do not exist in this image and the build
  *     rules forbid writing stand-ins for them, so the reference is UNBUILDABLE here and no
  *     oracle/_ref exists.  The reference ships no tests, golden vectors or fixtures.
- *   - What pins this oracle: the function-level known answers recorded in SURVEY.md 8(c)/Q1/
+ *   - Three translation units of the reference DO compile unmodified with this image's hipcc (-x hip): utils/cie_const.cu,
+ *     utils/color_const.cu (constant tables) -- oracle/Makefile's `ref` target builds them from where they lie into
+ *     oracle/_ref/libref_tables.so, and tests/test_ref_tables.py requires the CIE / D65 rows and the XYZ->sRGB matrix of
+ *     this oracle AND of the product to equal the reference's arrays bit for bit.  Nothing else of the reference compiles
+ *     without stand-ins.
+ *   - What else pins this oracle: the function-level known answers recorded in SURVEY.md 8(c)/Q1/
  *     Q14/Q23 (outputs of the reference's own functions observed in the survey session),
  *     committed as tests/golden/survey_kats.json and checked by tests/test_oracle_kats.py.
  *   - Whole-image parity against the real CUDA binary is UNPINNED (cannot be produced).
@@ -1196,6 +1201,7 @@ ORC_API float orc_cie_table(int which, int k) {
     const float *t = which == 0 ? cie_x : which == 1 ? cie_y : which == 2 ? cie_z : normalized_cie_d65;
     return t[k];
 }
+ORC_API void orc_color_matrix(float out9[9]) { memcpy(out9, d65_XYZ_to_sRGB, sizeof(d65_XYZ_to_sRGB)); }   /* utils/color_const.cu:17-19 */
 ORC_API float orc_cie_interp(int which, float lambda) {
     const float *t = which == 0 ? cie_x : which == 1 ? cie_y : which == 2 ? cie_z : normalized_cie_d65;
     return orc_spectrum_interp(t, lambda, N_CIE_SAMPLES);

@@ -70,6 +70,7 @@ def lib():
         L.orc_cie_table.argtypes = [C.c_int, C.c_int]
         L.orc_cie_interp.restype = C.c_float
         L.orc_cie_interp.argtypes = [C.c_int, C.c_float]
+        L.orc_color_matrix.argtypes = [_fp]
         L.orc_hero_wavelengths.argtypes = [C.c_uint64, _fp]
         L.orc_spectrum_to_XYZ.argtypes = [_fp, _fp, C.c_uint32, _fp]
         L.orc_XYZ_to_sRGB.argtypes = [_fp, _fp, _fp]

@@ -45,3 +45,28 @@ def test_product_does_not_reference_the_oracle():
             if f.endswith((".py", ".cpp", ".h", ".hip", "Makefile")):
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "oracle" not in text.lower().replace("the cpu oracle", "").replace("cpu oracle", ""), os.path.join(dirpath, f)
+
+
+def test_missing_rccl_is_reported_not_fatal(srt):
+    """when RCCL cannot be loaded every srt_comm_* entry point returns SRT_ERR_UNSUPPORTED with a message (it used to
+    dereference a null dlerror() and crash).  SRT_RCCL_LIB points the loader at a library that does not exist; the loader caches
+    its result per process, so this runs in a child process.  No GPU is touched."""
+    import subprocess
+    import sys
+    code = (
+        "import ctypes as C, importlib, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "srt = importlib.import_module('cuda-spectral-ray-tracer_amd')\n"
+        "L = srt.binding.lib()\n"
+        "assert L.srt_comm_available() == -5, L.srt_comm_available()\n"
+        "buf = (C.c_ubyte * 128)()\n"
+        "assert L.srt_comm_unique_id(buf) == -5\n"
+        "h = C.c_void_p()\n"
+        "dev = (C.c_int * 1)(0)\n"
+        "assert L.srt_comm_init_all(dev, 1, C.byref(h)) == -5 and not h.value\n"
+        "msg = L.srt_comm_last_error(None)\n"
+        "assert b'cannot load RCCL' in msg and b'no-such-dir' in msg, msg\n"
+        "print('ok')\n") % ROOT
+    env = dict(os.environ, SRT_RCCL_LIB="/no-such-dir/librccl.so.1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]

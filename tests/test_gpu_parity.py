@@ -183,8 +183,9 @@ def test_partition_invariance_and_chunks(srt, gpu, orc):
     W, H, spp, depth = 75, 41, 4, 8
     cam = scene.default_camera(W, H)
     ref = srt.render_image(scene, cam, W, H, spp, depth, renderer=gpu)
-    for world in (2, 5):
+    for world, planes in ((2, 9), (5, 9), (3, 3)):      # planes = 3: the default exchange unit (quantised framebuffer only)
         parts = []
+        gpu.set_gather_planes(planes)
         for rank in range(world):
             gpu.upload_scene(scene); gpu.set_camera(cam)
             gpu.init_device_params(W, H, spp, depth, 1984)
@@ -199,9 +200,12 @@ def test_partition_invariance_and_chunks(srt, gpu, orc):
         gathered = torch.from_numpy(np.concatenate(parts)).cuda()
         gpu.scatter_tiles(gathered.data_ptr())
         gpu.synchronize()
+        assert n_floats == gpu.tile_buffer()[3] * planes * 64
         assert_planes_equal(gpu.read_fb(), ref["fb"], "world %d" % world)
-        assert_planes_equal(gpu.read_fb_aux(2), ref["xyz"], "world %d xyz" % world)
+        if planes == 9:
+            assert_planes_equal(gpu.read_fb_aux(2), ref["xyz"], "world %d xyz" % world)
     gpu.set_partition(0, 1)
+    gpu.set_gather_planes(3)
 
 
 def test_ragged_chunks_multi_rank_match_oracle(srt, orc):
@@ -221,6 +225,7 @@ def test_ragged_chunks_multi_rank_match_oracle(srt, orc):
         r.upload_scene(scene); r.set_camera(cam)
         r.init_device_params(cw, ch, spp, depth, 1984)
         r.set_partition(rank, world)
+        r.set_gather_planes(9)               # the XYZ sums are compared below
         ranks.append(r)
     osc = oracle_scene_for(orc, scene, 0)
     n = 28 * 16 * bx * by
@@ -376,6 +381,7 @@ def test_full_frame_full_spp_bit_exact(srt, gpu, orc):
     osc = oracle_scene_for(orc, scene, 1)
     threads = os.cpu_count() or 1
     slices, differing, checked, t0 = 16, 0, 0, time.time()
+    threads = int(os.environ.get("SRT_LONG_THREADS", str(threads)))
     for k in range(slices):                           # the oracle in slices, so that a long run keeps printing
         ref = osc.render(cam, W, H, spp, depth, block_lo=k, block_stride=slices, threads=threads)
         for b in range(k, n_blocks, slices):
@@ -429,6 +435,16 @@ def test_full_resolution_mesh100k_blocks_bit_exact(srt, gpu, orc):
     assert _blocks_bit_exact(srt, gpu, orc, srt.SCENE_MESH100K, srt.BVH_SAH, 3840, 2160, 64, 16, 2000, 4100, 6) >= 4
 
 
+def test_cfg5_full_workload_blocks_bit_exact(srt, gpu, orc):
+    """BASELINE cfg 5 AS SPECIFIED, on one GPU: the 100k-triangle mesh, 3840x2160, **4096 spp**, depth 16 (34 G paths, ~100 G
+    rays: ten-odd seconds of kernel time); five of the reference's 28x16 blocks spread over the frame re-rendered by the oracle at
+    the full 4096 spp (about a minute on 16 host threads -- its NaN-direction rays walk all 200 k nodes) and compared bit for bit.
+    The 8-GPU partition of the same frame is covered by the partition / comm tests: pixels are independent."""
+    assert _blocks_bit_exact(srt, gpu, orc, srt.SCENE_MESH100K, srt.BVH_SAH, 3840, 2160, 4096, 16, 2000, 4100, 6) >= 4
+    st = gpu.stats()
+    assert st["paths"] == 3840 * 2160 * 4096 and st["rays"] > 2 * st["paths"]
+
+
 def test_cfg1_cornell_exact_size_full_image(srt, gpu, orc):
     """BASELINE cfg 1 at its exact size: the reference's CORNELL scene (own coloured-wall spectra, see DESIGN D-colours),
     256x256, 16 spp, depth 8, reference BVH builder; the WHOLE image against the oracle, bit for bit."""
@@ -474,7 +490,8 @@ def test_invalid_calls_fail_without_side_effects(srt, gpu):
     assert all(np.isfinite(p).all() for p in img["fb"])
 
 
-def _comm_image(srt, comm, scene, cam, W, H, spp, depth):
+def _comm_image(srt, comm, scene, cam, W, H, spp, depth, planes=9):
+    comm.set_gather_planes(planes)           # 9: the parity planes travel too (XYZ sums are compared); default of the library: 3
     comm.upload_scene(scene); comm.set_camera(cam)
     comm.init_device_params(W, H, spp, depth, 1984)
     comm.render_frame(W, H)
@@ -517,6 +534,9 @@ def test_comm_two_gpus_bit_identical(srt, gpu, orc):
     fb, xyz, st = _comm_image(srt, comm, scene, cam, W, H, spp, depth)
     assert_planes_equal(fb, ref["fb"], "2 GPUs fb"); assert_planes_equal(xyz, ref["xyz"], "2 GPUs xyz")
     assert st["rays"] == ref["stats"]["rays"]
+    fb3, _, _ = _comm_image(srt, comm, scene, cam, W, H, spp, depth, planes=3)      # the default exchange unit
+    assert_planes_equal(fb3, ref["fb"], "2 GPUs fb, 3-plane gather")
+    assert comm.last_gather_ms() >= 0.0
     comm.close()
 
 

@@ -21,7 +21,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, W, H, spp, depth, out_path):
+def _worker(rank, world, port, W, H, spp, depth, groups, out_path):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     for p in (ROOT, os.path.join(ROOT, "tests")):
         if p not in sys.path:
@@ -40,16 +40,18 @@ def _worker(rank, world, port, W, H, spp, depth, out_path):
     full = osc.render(cam, W, H, spp, depth, threads=2)              # stand-in renderer: every pixel, then keep own tiles
     planes = np.stack(list(full["fb"]) + list(full["lin"]) + list(full["xyz"]))      # [9, n_lanes] block-linear
     g = tiles.tile_geometry(W, H, tx, ty, bx, by, world)
-    local = torch.zeros((g["tiles_padded"], tiles.PLANES, tiles.LANES), dtype=torch.float32)
+    # a rank's tile buffer: [group][tile][plane of the group][lane]; `groups` of them travel (1 = the quantised framebuffer)
+    local = torch.zeros((tiles.GROUPS, g["tiles_padded"], tiles.GROUP_PLANES, tiles.LANES), dtype=torch.float32)
     lane = torch.arange(tiles.LANES)
     for k, t in enumerate(tiles.local_tile_ids(g["n_tiles"], rank, world)):
         i = (t % g["tiles_x"]) * 8 + lane % 8
         j = (t // g["tiles_x"]) * 8 + lane // 8
         ok = (i < g["cover_w"]) & (j < g["cover_h"])
         idx = tiles.block_linear_index(i, j, tx, ty, bx)
-        vals = torch.from_numpy(planes)[:, idx[ok]]
-        local[k][:, ok] = vals
-    gathered = tiles.gather_tiles(local, rank, world)                 # ONE collective
+        vals = torch.from_numpy(planes)[:, idx[ok]]                  # [9, n_ok]
+        for grp in range(tiles.GROUPS):
+            local[grp, k][:, ok] = vals[3 * grp: 3 * grp + 3]
+    gathered = tiles.gather_tiles(local[:groups].contiguous(), rank, world)                 # ONE collective
     if rank == 0:
         fb = tiles.scatter_tiles_torch(gathered, W, H, tx, ty, bx, by, world)
         np.save(out_path, np.concatenate([fb.numpy(), planes]))
@@ -59,15 +61,17 @@ def _worker(rank, world, port, W, H, spp, depth, out_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_partition_gather_scatter_gloo(world, tmp_path):
+@pytest.mark.parametrize("world,groups", [(2, 3), (3, 3), (2, 1)])
+def test_partition_gather_scatter_gloo(world, groups, tmp_path):
+    """groups = 3: all nine planes travel (parity tests); groups = 1: the default exchange unit, the quantised framebuffer."""
     W, H, spp, depth = 50, 37, 2, 4
     out = str(tmp_path / "fb.npy")
-    mp.spawn(_worker, args=(world, _free_port(), W, H, spp, depth, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), W, H, spp, depth, groups, out), nprocs=world, join=True)
     both = np.load(out)
-    fb, planes = both[:9], both[9:]
-    # every in-image lane of every plane arrives exactly once and unchanged; lanes outside the image stay 0
-    assert np.array_equal(fb.view(np.uint32), planes.view(np.uint32))
+    fb, planes = both[:3 * groups], both[3 * groups:]
+    # every in-image lane of every gathered plane arrives exactly once and unchanged; lanes outside the image stay 0
+    assert planes.shape[0] == 9
+    assert np.array_equal(fb.view(np.uint32), planes[:3 * groups].view(np.uint32))
 
 
 def test_tile_geometry_and_ownership(srt):

@@ -21,8 +21,12 @@ for kind in range(11):
         res = r.calibrate(kind, w, a.iters)
         res["name"] = NAMES[kind]
         rows.append(res)
-        print("%-70s w/SIMD %d: %.4f instr/cycle/SIMD, %.1f G wave-instr/s chip, clock %.3f GHz, wall %.2f ms" %
-              (NAMES[kind], w, res["instr_per_cycle_per_simd"], res["instr_per_s"] / 1e9, res["clock_ghz"], res["wall_ms"]), flush=True)
+        # rate = all instructions of a SIMD's waves / cycles of its LAST wave; check: rate x clock x SIMDs == chip rate
+        chk = res["instr_per_cycle_per_simd"] * res["clock_ghz"] * res["n_simd"]
+        print("%-70s w/SIMD %d: %.4f instr/cycle/SIMD (mean-wave-based %.4f), wave Mcycles min/mean/max %.2f/%.2f/%.2f, %.1f G wave-instr/s chip "
+              "(= %.1f from rate x clock x SIMDs), clock %.3f GHz, wall %.2f ms" %
+              (NAMES[kind], w, res["instr_per_cycle_per_simd"], res["instr_per_cycle_per_simd_mean_wave"], res["wave_cycles_min"] / 1e6,
+               res["wave_cycles_mean"] / 1e6, res["wave_cycles_max"] / 1e6, res["instr_per_s"] / 1e9, chk, res["clock_ghz"], res["wall_ms"]), flush=True)
 doc = {"device": "MI355X (gfx950)", "iters": a.iters, "rows": rows}
 if a.out:
     os.makedirs(os.path.dirname(a.out), exist_ok=True)
