@@ -96,12 +96,12 @@ def cpu_baseline(srt, scene, cam, width, height, depth, mode, budget_s=18.0, gpu
     next to its ONE-thread rate on the same scene."""
     cores, cores_note = usable_cores()
     osc = oracle_scene(srt, scene, mode)
-    # one thread, same scene: a quarter-resolution frame at 1 spp (same camera, so the same mix of sky / geometry / glass paths)
+    # one thread, same scene: a half-resolution frame at 1 spp (same camera, so the same mix of sky / geometry / glass paths)
     t0 = time.time()
-    r1 = osc.render(scene.default_camera(width // 4, height // 4), width // 4, height // 4, 1, depth, threads=1)
+    r1 = osc.render(scene.default_camera(width // 2, height // 2), width // 2, height // 2, 1, depth, threads=1)
     dt_one = max(time.time() - t0, 1e-6)
     one_thread = {"value": r1["stats"]["rays"] / dt_one / 1e6, "unit": "Mray/s", "cores": 1,
-                  "sample": "%dx%d, 1 spp, depth %d, same scene / BVH, 1 thread, %.1f s" % (width // 4, height // 4, depth, dt_one)}
+                  "sample": "%dx%d, 1 spp, depth %d, same scene / BVH, 1 thread, %.1f s" % (width // 2, height // 2, depth, dt_one)}
     t0 = time.time()
     r = osc.render(cam, width, height, 1, depth, threads=cores)           # calibration pass: 1 spp
     dt1 = max(time.time() - t0, 1e-3)
@@ -114,7 +114,7 @@ def cpu_baseline(srt, scene, cam, width, height, depth, mode, budget_s=18.0, gpu
            "sample": "%dx%d, %d spp, depth %d, same scene/camera/BVH, %d threads, %.1f s" % (width, height, spp, depth, cores, dt),
            "cores_source": cores_note, "one_thread_same_scene": one_thread,
            "note": "rounds 1-2 started os.cpu_count() = 256 threads on a box that grants this process far fewer cores (see cores_source), "
-                   "which is why 256 'threads' delivered only ~3x one thread; 1.2 %% of the rays (NaN directions, quirk Q1) walk the whole tree "
+                   "which is why their '256 threads' figure (10-12 Mray/s) was below this one; 1.2 % of the rays (NaN directions, quirk Q1) walk the whole tree "
                    "on the CPU like in the reference"}
     if gpu_renderer is not None:
         # the same frame at the same spp on the GPU, by BOTH builds of the kernel -- the production one (the kernel this run timed:

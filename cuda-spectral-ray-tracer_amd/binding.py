@@ -74,6 +74,7 @@ PROTOTYPES = {
     "srt_color_tables": (_i, [_fp, _fp]),
     "srt_background_spectrum": (_i, [_fp, _fp]),
     "srt_scene_build_bvh": (_i, [_vp, _i, _u64]),
+    "srt_scene_order_children": (_i, [_vp, _fp]),
     "srt_scene_node_count": (_sz, [_vp]),
     "srt_scene_bvh_depth": (_i, [_vp]),
     "srt_scene_get_bvh": (_i, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), _fp]),

@@ -1161,6 +1161,27 @@ int srt_scene_build_bvh(srt_scene *s, int mode, uint64_t seed) {
     set_global_error("bvh: unknown mode");
     return SRT_ERR_INVALID;
 }
+// Child order for a viewpoint.  The traversal is the reference's fixed left-first walk (bvh.cu:154-160), so which child is
+// "left" is a property of the tree: build_bvh_sah puts the half nearer to the scene's DEFAULT camera on the left.  A caller
+// that renders from another viewpoint (srt_set_camera) re-orders the finished tree with this call -- at every internal node the
+// child whose box is nearer to `eye` becomes the left one -- and uploads the scene again.  Topology, boxes and depth are
+// unchanged; like any change of the tree it can only alter a result where two triangles tie exactly in t (Q11).
+int srt_scene_order_children(srt_scene *s, const float eye[3]) {
+    if (!s || !s->bvh_valid || !eye) { set_global_error("srt_scene_order_children: BVH not built / null argument"); return SRT_ERR_INVALID; }
+    auto dist2 = [&](const float *bx) {
+        double d2 = 0;
+        for (int ax = 0; ax < 3; ax++) {
+            const double p = eye[ax], lo = bx[2 * ax], hi = bx[2 * ax + 1];
+            const double d = p < lo ? lo - p : (p > hi ? p - hi : 0.0);
+            d2 += d * d;
+        }
+        return d2;
+    };
+    for (BvhNode &nd : s->nodes)
+        if (nd.left >= 0 && nd.right >= 0 && dist2(s->nodes[nd.right].box) < dist2(s->nodes[nd.left].box)) std::swap(nd.left, nd.right);
+    s->cam.lookfrom[0] = eye[0]; s->cam.lookfrom[1] = eye[1]; s->cam.lookfrom[2] = eye[2];
+    return SRT_OK;
+}
 size_t srt_scene_node_count(const srt_scene *s) { return (s && s->bvh_valid) ? s->nodes.size() : 0; }
 int srt_scene_bvh_depth(const srt_scene *s) { return (s && s->bvh_valid) ? s->depth : 0; }
 

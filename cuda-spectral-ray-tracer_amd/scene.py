@@ -83,6 +83,12 @@ class Scene:
         B.check(B.lib().srt_scene_build_bvh(self._h, int(mode), int(seed)))
         return self
 
+    def order_children(self, eye):
+        """Re-order every node's children for a viewpoint (nearer child first); upload the scene again afterwards."""
+        e = (C.c_float * 3)(*[float(x) for x in eye])
+        B.check(B.lib().srt_scene_order_children(self._h, e))
+        return self
+
     @property
     def n_nodes(self):
         return B.lib().srt_scene_node_count(self._h)

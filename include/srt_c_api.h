@@ -146,6 +146,10 @@ SRT_API int srt_background_spectrum(const float rgb[3], float out[SRT_N_CIE_SAMP
  * SRT_BVH_SAH is this build's builder.  Either way the node semantics are the reference's: binary tree,
  * one triangle per leaf, leaf box = padded triangle box, internal box = union of children (Q22). */
 SRT_API int srt_scene_build_bvh(srt_scene *s, int mode, uint64_t seed);
+/* The traversal is the reference's left-first walk, so the child order is part of the tree; SRT_BVH_SAH orders every node's
+ * children by distance to the scene's default camera.  For another viewpoint: re-order the built tree for `eye` (the nearer
+ * child becomes the left one; topology, boxes and depth unchanged), then srt_upload_scene again. */
+SRT_API int srt_scene_order_children(srt_scene *s, const float eye[3]);
 SRT_API size_t srt_scene_node_count(const srt_scene *s);
 SRT_API int srt_scene_bvh_depth(const srt_scene *s);
 /* Pre-order dump (same convention as the oracle): left/right = pre-order ranks or -1, prim = original

@@ -437,10 +437,10 @@ def test_full_resolution_mesh100k_blocks_bit_exact(srt, gpu, orc):
 
 def test_cfg5_full_workload_blocks_bit_exact(srt, gpu, orc):
     """BASELINE cfg 5 AS SPECIFIED, on one GPU: the 100k-triangle mesh, 3840x2160, **4096 spp**, depth 16 (34 G paths, ~100 G
-    rays: ten-odd seconds of kernel time); five of the reference's 28x16 blocks spread over the frame re-rendered by the oracle at
-    the full 4096 spp (about a minute on 16 host threads -- its NaN-direction rays walk all 200 k nodes) and compared bit for bit.
+    rays: ten-odd seconds of kernel time); four of the reference's 28x16 blocks spread over the frame re-rendered by the oracle at
+    the full 4096 spp (about three minutes on 16 host threads -- its NaN-direction rays walk all 200 k nodes) and compared bit for bit.
     The 8-GPU partition of the same frame is covered by the partition / comm tests: pixels are independent."""
-    assert _blocks_bit_exact(srt, gpu, orc, srt.SCENE_MESH100K, srt.BVH_SAH, 3840, 2160, 4096, 16, 2000, 4100, 6) >= 4
+    assert _blocks_bit_exact(srt, gpu, orc, srt.SCENE_MESH100K, srt.BVH_SAH, 3840, 2160, 4096, 16, 2000, 4700, 5) >= 4
     st = gpu.stats()
     assert st["paths"] == 3840 * 2160 * 4096 and st["rays"] > 2 * st["paths"]
 

@@ -151,3 +151,30 @@ def test_sigmoid_fit_round_trip(srt, orc):
     for sdv in (red, green, blue):
         assert sdv.min() >= 0 and sdv.max() <= 1 and np.abs(np.diff(sdv)).max() < 0.2
     assert red[60] > 5 * red[20] and blue[20] > 3 * blue[70] and green[38] > 3 * green[80]
+
+
+def test_order_children_for_a_viewpoint(srt, orc):
+    """srt_scene_order_children: same topology / boxes / depth, every internal node's nearer child (to the eye) on the left; the
+    tree stays a valid input for the oracle (which imports it) -- GPU/oracle parity on a re-ordered tree is covered by the GPU suite."""
+    scene = srt.Scene.builtin(srt.SCENE_RANDOM_SPHERES, 0).build_bvh(srt.BVH_SAH)
+    l0, r0, p0, b0 = scene.bvh()
+    depth0, n0 = scene.bvh_depth, scene.n_nodes
+    eye = (-7.0, 3.5, 11.0)
+    scene.order_children(eye)
+    l1, r1, p1, b1 = scene.bvh()
+    assert scene.n_nodes == n0 and scene.bvh_depth == depth0
+    assert sorted(p0[p0 >= 0].tolist()) == sorted(p1[p1 >= 0].tolist())                  # the same triangles, each in one leaf
+    assert np.array_equal(np.sort(b0.reshape(-1, 6), axis=0), np.sort(b1.reshape(-1, 6), axis=0))   # the same set of boxes
+    b = b1.reshape(-1, 6).astype(np.float64)
+    e = np.array(eye)
+
+    def dist2(k):
+        lo, hi = b[k, 0::2], b[k, 1::2]
+        d = np.where(e < lo, lo - e, np.where(e > hi, e - hi, 0.0))
+        return float(np.sum(d * d))
+    inner = np.nonzero(l1 >= 0)[0]
+    assert inner.size == (n0 - 1) // 2
+    assert all(dist2(l1[k]) <= dist2(r1[k]) for k in inner)
+    assert not np.array_equal(l0, l1)                                                      # something really moved
+    osc = orc.OracleScene(scene.triangles(), scene.materials(), scene.background())
+    assert osc.set_bvh(l1, r1, p1, 0) == 1
