@@ -13,6 +13,10 @@
 //   6 v_cmp_lt_f32 + v_cndmask_b32 pairs (VCC)       7 ds_read_b64, lane-linear addresses (conflict free)
 //   8 ds_read_b64, per-lane random 16-byte records   9 v_max3_f32, 8 independent accumulators
 //  10 v_add_f32 with only 26 of 64 lanes enabled (EXEC-masked: does a partially filled instruction cost less?)
+//  11 4 x buffer_load_dwordx4 of a random 64-byte record per lane (16 MB table: L2 / MALL served), all 64 lanes
+//  12 the same with 16 lanes enabled, CONTIGUOUS (lanes 0-15: four full quads)
+//  13 the same with 16 lanes enabled, ONE PER QUAD (every fourth lane)   -- does the texture-address unit skip empty quads?
+//  14 the same with 32 contiguous lanes                                   15 the same with 32 lanes, two per quad
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -20,12 +24,12 @@
 
 namespace srt {
 
-constexpr int kCalibKinds = 11;
+constexpr int kCalibKinds = 16;
 
 #define REP4(x) x x x x
 
 template <int KIND>
-__global__ __launch_bounds__(1024) void calib_kernel(uint32_t iters, float *sink, unsigned long long *cycles) {
+__global__ __launch_bounds__(1024) void calib_kernel(uint32_t iters, float *sink, unsigned long long *cycles, const float4 *table, uint32_t n_records) {
     extern __shared__ float4 lds4[];
     const uint32_t tid = threadIdx.x;
     float a0 = (float)tid, a1 = a0 + 1.f, a2 = a0 + 2.f, a3 = a0 + 3.f, a4 = a0 + 4.f, a5 = a0 + 5.f, a6 = a0 + 6.f, a7 = a0 + 7.f;
@@ -44,6 +48,15 @@ __global__ __launch_bounds__(1024) void calib_kernel(uint32_t iters, float *sink
     uint32_t rnd_addr = ((tid * 2654435761u) >> 20) * 16u;              // 4096 records of 16 B, hashed per lane
     unsigned long long saved_exec = 0;
     if (KIND == 10) asm volatile("s_mov_b64 %0, exec\n s_mov_b64 exec, 0x3ffffff" : "=s"(saved_exec));
+    // kinds 11-15: random 64-byte records through a buffer descriptor, like the INNER visit of a tree that does not fit LDS
+    typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4 *>(table), 0, (int)(n_records * 64u), 0x00020000);
+    uint32_t rnd = (blockIdx.x * blockDim.x + tid) * 2654435761u + 12345u;
+    u4v g0 = {0, 0, 0, 0}, g1 = g0, g2 = g0, g3 = g0;
+    if (KIND == 12) asm volatile("s_mov_b64 %0, exec\n s_mov_b64 exec, 0xffff" : "=s"(saved_exec));
+    if (KIND == 13) asm volatile("s_mov_b64 %0, exec\n s_mov_b32 exec_lo, 0x11111111\n s_mov_b32 exec_hi, 0x11111111" : "=s"(saved_exec));
+    if (KIND == 14) asm volatile("s_mov_b64 %0, exec\n s_mov_b64 exec, 0xffffffff" : "=s"(saved_exec));
+    if (KIND == 15) asm volatile("s_mov_b64 %0, exec\n s_mov_b32 exec_lo, 0x33333333\n s_mov_b32 exec_hi, 0x33333333" : "=s"(saved_exec));
     __builtin_amdgcn_sched_barrier(0);
     unsigned long long t0;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
@@ -84,6 +97,17 @@ __global__ __launch_bounds__(1024) void calib_kernel(uint32_t iters, float *sink
                               "ds_read_b64 %4, %8 offset:2048\n ds_read_b64 %5, %8 offset:2560\n ds_read_b64 %6, %8 offset:3072\n ds_read_b64 %7, %8 offset:3584\n"
                               "s_waitcnt lgkmcnt(0)\n"
                               : "=&v"(p0), "=&v"(p1), "=&v"(p2), "=&v"(p3), "=&v"(p4), "=&v"(p5), "=&v"(p6), "=&v"(p7) : "v"(addr) : "memory");)
+        } else if (KIND >= 11 && KIND <= 15) {
+            // 8 rounds of 4 loads = 32 vector-memory instructions per trip; two rounds in flight
+#pragma unroll
+            for (int rr = 0; rr < 8; rr++) {
+                rnd = rnd * 1664525u + 1013904223u;
+                const uint32_t off = ((rnd >> 7) % n_records) * 64u;
+                asm volatile("buffer_load_dwordx4 %0, %4, %5, 0 offen\n buffer_load_dwordx4 %1, %4, %5, 0 offen offset:16\n"
+                             "buffer_load_dwordx4 %2, %4, %5, 0 offen offset:32\n buffer_load_dwordx4 %3, %4, %5, 0 offen offset:48\n"
+                             "s_waitcnt vmcnt(4)\n"
+                             : "=&v"(g0), "=&v"(g1), "=&v"(g2), "=&v"(g3) : "v"(off), "s"(rsrc) : "memory");
+            }
         } else if (KIND == 9) {
             REP4(asm volatile("v_max3_f32 %0, %0, %8, %1\n v_max3_f32 %1, %1, %8, %2\n v_max3_f32 %2, %2, %8, %3\n v_max3_f32 %3, %3, %8, %4\n"
                               "v_max3_f32 %4, %4, %8, %5\n v_max3_f32 %5, %5, %8, %6\n v_max3_f32 %6, %6, %8, %7\n v_max3_f32 %7, %7, %8, %0\n"
@@ -94,36 +118,42 @@ __global__ __launch_bounds__(1024) void calib_kernel(uint32_t iters, float *sink
     unsigned long long t1;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
     __builtin_amdgcn_sched_barrier(0);
-    if (KIND == 10) asm volatile("s_mov_b64 exec, %0" ::"s"(saved_exec));
+    if (KIND >= 11) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (KIND == 10 || (KIND >= 12 && KIND <= 15)) asm volatile("s_mov_b64 exec, %0" ::"s"(saved_exec));
     const uint32_t gwave = (blockIdx.x * blockDim.x + tid) >> 6;
     if ((tid & 63u) == 0u) cycles[gwave] = t1 - t0;
     // keep every accumulator alive
     float acc = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + p0.x + p1.y + p2.x + p3.y + p4.x + p5.y + p6.x + p7.y +
-                (float)(s0 + s1 + s2 + s3 + s4 + s5 + s6 + s7);
+                (float)(s0 + s1 + s2 + s3 + s4 + s5 + s6 + s7) + (float)(g0.x + g1.y + g2.z + g3.w);
     if (acc == 12345.678f) sink[tid] = acc;
 }
 
 template <int KIND>
-static hipError_t run_kind(uint32_t n_blocks, uint32_t threads, uint32_t iters, float *sink, unsigned long long *cycles, hipStream_t st) {
+static hipError_t run_kind(uint32_t n_blocks, uint32_t threads, uint32_t iters, float *sink, unsigned long long *cycles, const float4 *table, uint32_t n_records, hipStream_t st) {
     const size_t lds = 96 * 1024;      // more than half a CU's LDS: exactly one workgroup per CU, so waves / SIMD = threads / 256
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&calib_kernel<KIND>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((calib_kernel<KIND>), dim3(n_blocks), dim3(threads), lds, st, iters, sink, cycles);
+    hipLaunchKernelGGL((calib_kernel<KIND>), dim3(n_blocks), dim3(threads), lds, st, iters, sink, cycles, table, n_records);
     return hipGetLastError();
 }
 
-hipError_t launch_calib(int kind, uint32_t n_blocks, uint32_t threads, uint32_t iters, float *sink, unsigned long long *cycles, hipStream_t st) {
+hipError_t launch_calib(int kind, uint32_t n_blocks, uint32_t threads, uint32_t iters, float *sink, unsigned long long *cycles, const float4 *table, uint32_t n_records, hipStream_t st) {
     switch (kind) {
-    case 0: return run_kind<0>(n_blocks, threads, iters, sink, cycles, st);
-    case 1: return run_kind<1>(n_blocks, threads, iters, sink, cycles, st);
-    case 2: return run_kind<2>(n_blocks, threads, iters, sink, cycles, st);
-    case 3: return run_kind<3>(n_blocks, threads, iters, sink, cycles, st);
-    case 4: return run_kind<4>(n_blocks, threads, iters, sink, cycles, st);
-    case 5: return run_kind<5>(n_blocks, threads, iters, sink, cycles, st);
-    case 6: return run_kind<6>(n_blocks, threads, iters, sink, cycles, st);
-    case 7: return run_kind<7>(n_blocks, threads, iters, sink, cycles, st);
-    case 8: return run_kind<8>(n_blocks, threads, iters, sink, cycles, st);
-    case 9: return run_kind<9>(n_blocks, threads, iters, sink, cycles, st);
-    case 10: return run_kind<10>(n_blocks, threads, iters, sink, cycles, st);
+    case 0: return run_kind<0>(n_blocks, threads, iters, sink, cycles, table, n_records, st);
+    case 1: return run_kind<1>(n_blocks, threads, iters, sink, cycles, table, n_records, st);
+    case 2: return run_kind<2>(n_blocks, threads, iters, sink, cycles, table, n_records, st);
+    case 3: return run_kind<3>(n_blocks, threads, iters, sink, cycles, table, n_records, st);
+    case 4: return run_kind<4>(n_blocks, threads, iters, sink, cycles, table, n_records, st);
+    case 5: return run_kind<5>(n_blocks, threads, iters, sink, cycles, table, n_records, st);
+    case 6: return run_kind<6>(n_blocks, threads, iters, sink, cycles, table, n_records, st);
+    case 7: return run_kind<7>(n_blocks, threads, iters, sink, cycles, table, n_records, st);
+    case 8: return run_kind<8>(n_blocks, threads, iters, sink, cycles, table, n_records, st);
+    case 9: return run_kind<9>(n_blocks, threads, iters, sink, cycles, table, n_records, st);
+    case 10: return run_kind<10>(n_blocks, threads, iters, sink, cycles, table, n_records, st);
+    case 11: return run_kind<11>(n_blocks, threads, iters, sink, cycles, table, n_records, st);
+    case 12: return run_kind<12>(n_blocks, threads, iters, sink, cycles, table, n_records, st);
+    case 13: return run_kind<13>(n_blocks, threads, iters, sink, cycles, table, n_records, st);
+    case 14: return run_kind<14>(n_blocks, threads, iters, sink, cycles, table, n_records, st);
+    case 15: return run_kind<15>(n_blocks, threads, iters, sink, cycles, table, n_records, st);
     default: return hipErrorInvalidValue;
     }
 }

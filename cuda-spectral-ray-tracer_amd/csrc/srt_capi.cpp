@@ -13,12 +13,20 @@
 
 using namespace srt;
 
+#ifndef SRT_FRINGE_STRIDE_L2
+#define SRT_FRINGE_STRIDE_L2 96
+#endif
+static constexpr uint32_t kFringeStrideL2 = SRT_FRINGE_STRIDE_L2;
+// step-choice weights when the inner tree exceeds the LDS cache (256 = an INNER visit)
+static constexpr uint32_t kScoreShadeL2 = 320u, kScoreFringeL2 = 800u;   // FRINGE record stride for trees that do not fit LDS
+
 struct srt_ctx {
     int device = 0;
     std::string err;
     // scene images in HBM
     float *d_nodes = nullptr, *d_fringe = nullptr, *d_tris = nullptr, *d_mat_sd = nullptr, *d_mat_par = nullptr, *d_shade = nullptr, *d_cmf = nullptr;
     int root_ref = 0, stack_depth = 1, n_inner = 0, n_records = 0;
+    uint32_t fringe_stride = 96;       // bytes between FRINGE records in d_fringe
     uint32_t n_tris = 0;
     uint32_t n_materials = 0;
     bool scene_ready = false, camera_ready = false, params_ready = false;
@@ -92,7 +100,7 @@ void fill_params(const srt_ctx *c, RenderParams &p) {
     p.shade = (const float4 *)c->d_shade; p.cmf = (const float4 *)c->d_cmf;
     p.root_ref = c->root_ref; p.stack_depth = c->stack_depth; p.n_materials = c->n_materials;
     p.n_inner = c->n_inner; p.n_cached = 0;   // n_cached is set by the launcher
-    p.n_tris = c->n_tris; p.n_records = c->n_records;
+    p.n_tris = c->n_tris; p.n_records = c->n_records; p.fringe_stride = c->fringe_stride;
     for (int k = 0; k < 3; k++) {
         p.du[k] = c->cam.pixel_delta_u[k]; p.dv[k] = c->cam.pixel_delta_v[k]; p.p00[k] = c->cam.pixel00_loc[k];
         p.center[k] = c->cam.camera_center[k]; p.disk_u[k] = c->cam.defocus_disk_u[k]; p.disk_v[k] = c->cam.defocus_disk_v[k];
@@ -171,7 +179,25 @@ int srt_upload_scene(srt_ctx *c, const srt_scene *s) {
     if (rc != SRT_OK) return fail(c, rc, global_error());
     if (render_lds_bytes(f.stack_depth, 1, 0, f.n_records) > 64 * 1024) return fail(c, SRT_ERR_BVH, "srt_upload_scene: BVH too deep for the LDS traversal stack");
     if ((rc = upload(c, &c->d_nodes, f.nodes)) != SRT_OK) return rc;
-    if ((rc = upload(c, &c->d_fringe, f.fringe)) != SRT_OK) return rc;
+    {
+        // FRINGE records are 96 B.  Packed, every second one straddles two 128-byte cache lines; when the tree is too large for
+        // LDS every visit is an L2 round trip and a record that lies in ONE line halves the lines a FRINGE visit pulls through the
+        // CU's small L1: such trees get their fringe records padded to a 128-byte stride (SRT_FRINGE_STRIDE = 96 | 128 overrides).
+        LaunchPlan plan;
+        render_launch_plan(f.stack_depth, f.n_records, f.n_inner, plan);
+        uint32_t stride = plan.all_cached ? 96u : kFringeStrideL2;
+        if (const char *ev = getenv("SRT_FRINGE_STRIDE")) stride = (atoi(ev) == 128 && !plan.all_cached) ? 128u : 96u;
+        if ((uint64_t)(f.n_records - f.n_inner + 1) * stride >= (1ull << 31)) stride = 96u;
+        if (stride == 96u) {
+            if ((rc = upload(c, &c->d_fringe, f.fringe)) != SRT_OK) return rc;
+        } else {
+            const size_t n_fr = f.fringe.size() / 24;
+            std::vector<float> padded(n_fr * 32, 0.f);
+            for (size_t k = 0; k < n_fr; k++) memcpy(&padded[32 * k], &f.fringe[24 * k], 24 * sizeof(float));
+            if ((rc = upload(c, &c->d_fringe, padded)) != SRT_OK) return rc;
+        }
+        c->fringe_stride = stride;
+    }
     if ((rc = upload(c, &c->d_tris, f.tris)) != SRT_OK) return rc;
     if ((rc = upload(c, &c->d_mat_sd, f.mat_sd)) != SRT_OK) return rc;
     if ((rc = upload(c, &c->d_mat_par, f.mat_par)) != SRT_OK) return rc;
@@ -259,14 +285,14 @@ int srt_render_chunk(srt_ctx *c, uint32_t width, uint32_t height, uint32_t offx,
     p.tiles_local = c->tiles_local;
     p.pixel_counter = (uint32_t *)(c->d_counters + kCounters);
     p.waves_per_cu_override = c->waves_per_cu;
+    LaunchPlan plan;
+    render_launch_plan(c->stack_depth, c->n_records, c->n_inner, plan);
     {
-        int wpb = 1, n_cached = 0;
-        render_launch_shape(c->stack_depth, c->n_records, c->n_inner, wpb, n_cached);
-        const bool all_cached = n_cached == c->n_inner;
+        const bool all_cached = plan.all_cached;
         // (inner records that come from L2 make an INNER visit ~2x as expensive, so shading and FRINGE visits weigh more:
         // plateau 280-400 / 560-1100 on cfg 5's scene, 60-85 / 280-340 on cfg 2 / 3 / 4, profiles/r02/knob_sweeps.txt)
-        p.score_shade = c->score_shade ? c->score_shade : (all_cached ? 70u : 320u);
-        p.score_fringe = c->score_fringe ? c->score_fringe : (all_cached ? 280u : 800u);
+        p.score_shade = c->score_shade ? c->score_shade : (all_cached ? 70u : kScoreShadeL2);
+        p.score_fringe = c->score_fringe ? c->score_fringe : (all_cached ? 280u : kScoreFringeL2);
     }
     // ---- cost-ordered pixel queue --------------------------------------------------------------------------------
     // A pixel is one sequential RNG stream, so the launch cannot finish before its most expensive pixel does.  A short
@@ -290,7 +316,7 @@ int srt_render_chunk(srt_ctx *c, uint32_t width, uint32_t height, uint32_t offx,
         RenderParams pp = p;
         pp.spp = c->probe_spp; pp.tile_cost = c->d_tile_cost;
         HIP_TRY(c, launch_render(pp, (uint32_t)c->n_cu, 2, st));
-        HIP_TRY(c, launch_order_tiles(c->d_tile_cost, sorted, rows, c->tiles_local, (uint32_t)c->n_cu * 16u, c->split_load_pct, queue_info, st));   // device-side, no host sync
+        HIP_TRY(c, launch_order_tiles(c->d_tile_cost, sorted, rows, c->tiles_local, (uint32_t)c->n_cu * (uint32_t)plan.waves_per_cu, c->split_load_pct, queue_info, st));   // device-side, no host sync
         HIP_TRY(c, hipMemsetAsync(c->d_counters + kCounters, 0, sizeof(unsigned long long), st));   // rewind the queue head
         p.tile_order = rows;
         p.queue_rows = queue_info;
@@ -490,12 +516,16 @@ int srt_calibrate(srt_ctx *c, int kind, uint32_t waves_per_simd, uint32_t iters,
     float *d_sink = nullptr;
     HIP_TRY(c, hipMalloc((void **)&d_cyc, n_waves * sizeof(unsigned long long)));
     hipError_t e = hipMalloc((void **)&d_sink, 1024 * sizeof(float));
+    // kinds 11+: a 16 MB table of 64-byte records (the size of the 100k-triangle mesh's tree: served by L2 / MALL)
+    const uint32_t n_table = 1u << 18;
+    float4 *d_table = nullptr;
+    if (e == hipSuccess && kind >= 11) { e = hipMalloc((void **)&d_table, (size_t)n_table * 64); if (e == hipSuccess) e = hipMemset(d_table, 0, (size_t)n_table * 64); }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (e == hipSuccess) e = hipEventCreate(&e0);
     if (e == hipSuccess) e = hipEventCreate(&e1);
-    if (e == hipSuccess) e = launch_calib(kind, n_blocks, threads, iters / 8u + 1u, d_sink, d_cyc, nullptr);   // warm-up (clocks, code)
+    if (e == hipSuccess) e = launch_calib(kind, n_blocks, threads, iters / 8u + 1u, d_sink, d_cyc, d_table, n_table, nullptr);   // warm-up (clocks, code)
     if (e == hipSuccess) e = hipEventRecord(e0, nullptr);
-    if (e == hipSuccess) e = launch_calib(kind, n_blocks, threads, iters, d_sink, d_cyc, nullptr);
+    if (e == hipSuccess) e = launch_calib(kind, n_blocks, threads, iters, d_sink, d_cyc, d_table, n_table, nullptr);
     if (e == hipSuccess) e = hipEventRecord(e1, nullptr);
     if (e == hipSuccess) e = hipEventSynchronize(e1);
     float ms = 0.f;
@@ -506,6 +536,7 @@ int srt_calibrate(srt_ctx *c, int kind, uint32_t waves_per_simd, uint32_t iters,
     if (e1) (void)hipEventDestroy(e1);
     (void)hipFree(d_cyc);
     if (d_sink) (void)hipFree(d_sink);
+    if (d_table) (void)hipFree(d_table);
     if (e != hipSuccess) return hip_fail(c, e, "srt_calibrate");
     double sum = 0, mx = 0, mn = 1e300;
     for (unsigned long long v : h) { sum += (double)v; mx = std::max(mx, (double)v); mn = std::min(mn, (double)v); }

@@ -329,7 +329,8 @@ typedef __attribute__((address_space(3))) const f2 lds_cf2;
 typedef __attribute__((address_space(3))) const char lds_cchar;
 struct NodeSrc {
     buf_rsrc global_nodes;               // INNER records, 64 B each
-    buf_rsrc global_fringe;              // FRINGE records, 96 B each, indexed by record - n_inner
+    buf_rsrc global_fringe;              // FRINGE records, 96 B each (fringe_stride apart), indexed by record - n_inner
+    uint32_t fringe_stride;
     int n_inner;
     lds_cf4 *lds_q0, *lds_q1, *lds_q2;   // x / y / z planes
     lds_cu32 *lds_r0, *lds_r1;           // NARROW: r0 = lref | rref << 16; else r0 = lref, r1 = rref
@@ -670,7 +671,7 @@ struct FringeFetch { f4v q0, q1, q2, q3, q4, q5; int below; };
 template <bool NARROW>
 __device__ __forceinline__ void trav_fringe_fetch(FringeFetch &ff, const Trav &tv, const NodeSrc &ns, const StackRef &stack) {
     // one round of independent loads: 12 (left, right) pairs = six 16-byte loads (record layout: flatten_scene)
-    const uint32_t off = __umul24((uint32_t)(tv.node - ns.n_inner), 96u);   // (full-rate 24-bit multiply; < 2^24 fringe records)
+    const uint32_t off = __umul24((uint32_t)(tv.node - ns.n_inner), ns.fringe_stride);   // (full-rate 24-bit multiply; < 2^24 fringe records)
     ff.q0 = buf_load16(ns.global_fringe, off); ff.q1 = buf_load16(ns.global_fringe, off + 16u); ff.q2 = buf_load16(ns.global_fringe, off + 32u);
     ff.q3 = buf_load16(ns.global_fringe, off + 48u); ff.q4 = buf_load16(ns.global_fringe, off + 64u); ff.q5 = buf_load16(ns.global_fringe, off + 80u);
     // a FRINGE visit never pushes (at most one child is internal), so it only needs the entry a pop would bring up

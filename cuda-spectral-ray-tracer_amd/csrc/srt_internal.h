@@ -27,6 +27,7 @@ struct RenderParams {
     int n_inner;               // records below this index have two internal children (box tests only)
     int n_cached;              // records below this index are resident in LDS (top of the tree)
     int n_records;             // number of paired-child records
+    uint32_t fringe_stride;    // bytes between two FRINGE records: 96 (packed) or 128 (one cache line each: trees served by L2)
     uint32_t n_materials;
     uint32_t n_tris;
     // camera_data (rendering/rendering.cuh:28-36)
@@ -75,9 +76,12 @@ hipError_t launch_unswizzle(const float *const src[3], float *const dst[3], uint
                             uint32_t image_height, hipStream_t st);
 hipError_t launch_trace(const RenderParams &p, const float *rays, size_t n, float *out, hipStream_t st);
 hipError_t launch_op_sweep(int which, const float *a, const float *b, size_t n, float *out, hipStream_t st);
-hipError_t launch_calib(int kind, uint32_t n_blocks, uint32_t threads, uint32_t iters, float *sink, unsigned long long *cycles, hipStream_t st);
+hipError_t launch_calib(int kind, uint32_t n_blocks, uint32_t threads, uint32_t iters, float *sink, unsigned long long *cycles, const float4 *table,
+                        uint32_t n_records, hipStream_t st);
 int calib_kinds();
 size_t render_lds_bytes(int stack_depth, int waves_per_block, int n_cached, int n_records);
 void render_launch_shape(int stack_depth, int n_records, int n_inner, int &waves_per_block, int &n_cached);
+struct LaunchPlan { int waves_per_block, blocks_per_cu, waves_per_cu, waves_per_eu, n_cached; bool all_cached; };
+void render_launch_plan(int stack_depth, int n_records, int n_inner, LaunchPlan &lp);   // what launch_render will do for this scene
 
 }  // namespace srt

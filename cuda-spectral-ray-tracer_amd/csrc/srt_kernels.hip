@@ -95,6 +95,17 @@ void render_launch_shape(int stack_depth, int n_records, int n_inner, int &waves
     if (const char *ev = getenv("SRT_LDS_CACHE_MAX")) room = std::min(room, (size_t)std::max(0, atoi(ev)));   // experiment knob
     n_cached = (int)room;
 }
+// The launch plan of a scene: one 16-wave workgroup per CU (4 waves / SIMD at this kernel's 126 VGPRs) whenever the stacks leave
+// room for a useful cache; ALL_CACHED when the whole inner tree fits it.  (Round 3 measured a second shape for trees that do not
+// fit -- 256-thread workgroups, five per CU, 96 VGPRs, five waves per SIMD -- at -5 % on the 100k-triangle mesh and dropped it:
+// profiles/r03/experiments/cfg5_negative_results.txt.)
+void render_launch_plan(int stack_depth, int n_records, int n_inner, LaunchPlan &lp) {
+    render_launch_shape(stack_depth, n_records, n_inner, lp.waves_per_block, lp.n_cached);
+    lp.all_cached = lp.n_cached == n_inner;
+    lp.waves_per_eu = 4;
+    lp.blocks_per_cu = 16 / lp.waves_per_block;
+    lp.waves_per_cu = lp.waves_per_block * lp.blocks_per_cu;
+}
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 #pragma unroll
@@ -182,7 +193,9 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
 
     NodeSrc ns;
     ns.global_nodes = make_rsrc(P.nodes, (uint32_t)P.n_inner * 64u);
-    ns.global_fringe = make_rsrc(P.fringe, (uint32_t)(P.n_records - P.n_inner) * 96u);
+    // (a tree that fits LDS always has packed 96-byte FRINGE records -- srt_upload_scene -- so that variant keeps the literal)
+    ns.fringe_stride = ALL_CACHED ? 96u : P.fringe_stride;
+    ns.global_fringe = make_rsrc(P.fringe, (uint32_t)(P.n_records - P.n_inner) * ns.fringe_stride);
     ns.n_inner = P.n_inner;
     ns.lds_q0 = (lds_cf4 *)s_q0; ns.lds_q1 = (lds_cf4 *)s_q1; ns.lds_q2 = (lds_cf4 *)s_q2;
     ns.lds_r0 = (lds_cu32 *)s_r0; ns.lds_r1 = (lds_cu32 *)s_r1;
@@ -766,7 +779,8 @@ __global__ __launch_bounds__(64) void trace_rays_kernel(const RenderParams P, co
     if (active) trav_begin<false>(tv, stack_base<false>(my_stack), P.tris, P.root_ref, o, d, ts);
     NodeSrc ns;
     ns.global_nodes = make_rsrc(P.nodes, (uint32_t)P.n_inner * 64u);
-    ns.global_fringe = make_rsrc(P.fringe, (uint32_t)(P.n_records - P.n_inner) * 96u);
+    ns.global_fringe = make_rsrc(P.fringe, (uint32_t)(P.n_records - P.n_inner) * P.fringe_stride);
+    ns.fringe_stride = P.fringe_stride;
     ns.n_inner = P.n_inner;
     ns.lds_q0 = ns.lds_q1 = ns.lds_q2 = nullptr; ns.lds_r0 = ns.lds_r1 = nullptr; ns.n_cached = 0;
     while (__ballot(tv.node >= 0) != 0ull) {
@@ -837,26 +851,26 @@ hipError_t launch_init_rng(uint32_t *rng, uint32_t n_lanes, uint64_t seed, hipSt
 }
 
 template <int MODE, bool NARROW, bool ALL_CACHED>
-static hipError_t launch_render_cached(const RenderParams &p_in, uint32_t n_cu, hipStream_t st) {
+static hipError_t launch_render_cached(const RenderParams &p_in, const LaunchPlan &lp, uint32_t n_cu, hipStream_t st) {
     RenderParams p = p_in;
-    int wpb = 1, n_cached = 0;
-    render_launch_shape(p.stack_depth, p.n_records, p.n_inner, wpb, n_cached);
+    int wpb = lp.waves_per_block;
+    uint32_t waves_per_cu = (uint32_t)lp.waves_per_cu;
     if (p.waves_per_cu_override > 0 && p.waves_per_cu_override < 16 && wpb == 16) {
         // experiment knob: fewer waves per CU (one smaller workgroup per CU, same LDS cache), e.g. 8 = two waves per SIMD
         wpb = (int)p.waves_per_cu_override;
+        waves_per_cu = p.waves_per_cu_override;
     }
-    p.n_cached = n_cached;
-    const size_t lds = render_lds_bytes(p.stack_depth, wpb, n_cached, p.n_records);
+    p.n_cached = lp.n_cached;
+    const size_t lds = render_lds_bytes(p.stack_depth, wpb, lp.n_cached, p.n_records);
     // per launch, not once per process: the attribute belongs to the function ON THE CURRENT DEVICE, and one process may
     // drive several GPUs (srt_comm_init_all); the call is a host-side table update
     {
         const hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<MODE, NARROW, ALL_CACHED>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget);
         if (ae != hipSuccess) return ae;
     }
-    // persistent waves: fill every CU (16 waves per CU at this kernel's register budget), never more waves than tiles
-    uint32_t waves_per_cu = p.waves_per_cu_override > 0 ? p.waves_per_cu_override : 16u;
+    // persistent waves: fill every CU (waves_per_cu at this build's register budget), never more waves than queue rows
     uint32_t n_waves = n_cu * waves_per_cu;
-    if (n_waves > p.queue_rows_bound) n_waves = p.queue_rows_bound;     // never more waves than queue rows (upper bound known to the host)
+    if (n_waves > p.queue_rows_bound) n_waves = p.queue_rows_bound;     // (upper bound known to the host)
     const uint32_t n_blocks = (n_waves + (uint32_t)wpb - 1) / (uint32_t)wpb;
     hipLaunchKernelGGL((render_kernel<MODE, NARROW, ALL_CACHED>), dim3(n_blocks), dim3(64 * wpb), lds, st, p);
     return hipGetLastError();
@@ -864,9 +878,9 @@ static hipError_t launch_render_cached(const RenderParams &p_in, uint32_t n_cu, 
 
 template <int MODE, bool NARROW>
 static hipError_t launch_render_mode(const RenderParams &p, uint32_t n_cu, hipStream_t st) {
-    int wpb = 1, n_cached = 0;
-    render_launch_shape(p.stack_depth, p.n_records, p.n_inner, wpb, n_cached);
-    return n_cached == p.n_inner ? launch_render_cached<MODE, NARROW, true>(p, n_cu, st) : launch_render_cached<MODE, NARROW, false>(p, n_cu, st);
+    LaunchPlan lp;
+    render_launch_plan(p.stack_depth, p.n_records, p.n_inner, lp);
+    return lp.all_cached ? launch_render_cached<MODE, NARROW, true>(p, lp, n_cu, st) : launch_render_cached<MODE, NARROW, false>(p, lp, n_cu, st);
 }
 
 hipError_t launch_render(const RenderParams &p, uint32_t n_cu, int mode, hipStream_t st) {

@@ -9,16 +9,19 @@ srt = importlib.import_module("cuda-spectral-ray-tracer_amd")
 NAMES = {0: "v_add_f32 x8 independent", 1: "v_pk_mul_f32 x8 independent", 2: "v_fma_f32 x8 independent", 3: "v_add_f32 dependent chain",
          4: "s_add_u32 x8 independent", 5: "v_add_f32 + s_add_u32 interleaved (32 instr = 16 VALU + 16 SALU)", 6: "v_cmp_lt_f32 + v_cndmask_b32 pairs",
          7: "ds_read_b64 lane-linear (+ lgkmcnt(0) per 8)", 8: "ds_read_b64 random 16 B records (+ lgkmcnt(0) per 8)", 9: "v_max3_f32 x8",
-         10: "v_add_f32 x8, 26 of 64 lanes enabled"}
+         10: "v_add_f32 x8, 26 of 64 lanes enabled",
+         11: "buffer_load_dwordx4 x4 random 64 B records (16 MB table), 64 lanes", 12: "... 16 lanes, contiguous (4 full quads)",
+         13: "... 16 lanes, one per quad", 14: "... 32 lanes, contiguous", 15: "... 32 lanes, two per quad"}
 ap = argparse.ArgumentParser()
 ap.add_argument("--iters", type=int, default=40000)
 ap.add_argument("--out", default=None)
 a = ap.parse_args()
 r = srt.Renderer(0)
 rows = []
-for kind in range(11):
+ap2 = a
+for kind in (range(16) if not os.environ.get('CALIB_KINDS') else [int(x) for x in os.environ['CALIB_KINDS'].split(',')]):
     for w in (1, 2, 4):
-        res = r.calibrate(kind, w, a.iters)
+        res = r.calibrate(kind, w, a.iters if kind < 11 else max(1, a.iters // 40))
         res["name"] = NAMES[kind]
         rows.append(res)
         # rate = all instructions of a SIMD's waves / cycles of its LAST wave; check: rate x clock x SIMDs == chip rate
