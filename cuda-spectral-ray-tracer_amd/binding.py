@@ -38,7 +38,8 @@ class CameraData(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("paths", C.c_uint64), ("node_visits", C.c_uint64), ("tri_tests", C.c_uint64),
-                ("box_tests", C.c_uint64), ("util", C.c_uint64 * 9), ("reserved", C.c_uint64 * 2), ("shade", C.c_uint64 * 4)]
+                ("box_tests", C.c_uint64), ("util", C.c_uint64 * 9), ("reserved", C.c_uint64 * 2), ("shade", C.c_uint64 * 4),
+                ("waves", C.c_uint64 * 4)]
 
 
 class Calibration(C.Structure):
@@ -98,6 +99,7 @@ PROTOTYPES = {
     "srt_get_tile_costs": (_i, [_vp, C.POINTER(C.c_uint32), _sz]),
     "srt_get_stats": (_i, [_vp, C.POINTER(Stats)]),
     "srt_set_count_traversal": (_i, [_vp, _i]),
+    "srt_get_wave_debug": (_i, [_vp, C.POINTER(C.c_uint32), _sz]),
     "srt_last_kernel_ms": (_i, [_vp, C.POINTER(_f)]),
     "srt_trace_rays": (_i, [_vp, _fp, _sz, _fp]),
     "srt_device_op_sweep": (_i, [_vp, _i, _fp, _fp, _sz, _fp]),

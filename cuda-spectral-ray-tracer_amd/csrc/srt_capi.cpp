@@ -66,6 +66,8 @@ struct srt_ctx {
     bool timed = false;
     uint64_t last_paths = 0;
     float *d_rowmajor = nullptr;                        // row-major staging image of srt_read_fb_rowmajor (3 planes)
+    uint32_t *d_wave_debug = nullptr;                   // instrumented launches: 4 words per wave
+    uint32_t wave_debug_waves = 0;
     uint32_t rowmajor_w = 0, rowmajor_h = 0;
 };
 
@@ -160,7 +162,7 @@ void srt_destroy(srt_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    void *bufs[] = {c->d_nodes, c->d_fringe, c->d_tris, c->d_mat_sd, c->d_mat_par, c->d_shade, c->d_cmf, c->d_rng, c->d_fb, c->d_tiles, c->d_counters, c->d_tile_cost, c->d_tile_order, c->d_rowmajor};
+    void *bufs[] = {c->d_nodes, c->d_fringe, c->d_tris, c->d_mat_sd, c->d_mat_par, c->d_shade, c->d_cmf, c->d_rng, c->d_fb, c->d_tiles, c->d_counters, c->d_tile_cost, c->d_tile_order, c->d_rowmajor, c->d_wave_debug};
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -320,7 +322,18 @@ int srt_render_chunk(srt_ctx *c, uint32_t width, uint32_t height, uint32_t offx,
         HIP_TRY(c, hipMemsetAsync(c->d_counters + kCounters, 0, sizeof(unsigned long long), st));   // rewind the queue head
         p.tile_order = rows;
         p.queue_rows = queue_info;
+        p.prio_cost = c->d_tile_cost;
         if (c->split_load_pct) p.queue_rows_bound = (uint32_t)std::min<uint64_t>((uint64_t)c->tiles_local * 64, 0x7fffffffull);
+    }
+    if (c->count_traversal) {
+        const uint32_t n_waves = (uint32_t)c->n_cu * (uint32_t)plan.waves_per_cu;
+        if (n_waves > c->wave_debug_waves) {
+            if (c->d_wave_debug) { (void)hipFree(c->d_wave_debug); c->d_wave_debug = nullptr; c->wave_debug_waves = 0; }
+            HIP_TRY(c, hipMalloc((void **)&c->d_wave_debug, (size_t)n_waves * 4 * sizeof(uint32_t)));
+            c->wave_debug_waves = n_waves;
+        }
+        HIP_TRY(c, hipMemsetAsync(c->d_wave_debug, 0, (size_t)c->wave_debug_waves * 4 * sizeof(uint32_t), st));
+        p.wave_debug = c->d_wave_debug;
     }
     HIP_TRY(c, hipEventRecord(c->ev0, st));     // ev0..ev1 bracket the render kernel alone (roofline.achieved)
     HIP_TRY(c, launch_render(p, (uint32_t)c->n_cu, c->count_traversal ? 1 : 0, st));
@@ -445,7 +458,8 @@ int srt_get_stats(srt_ctx *c, srt_stats *out) {
     out->rays = h[0]; out->node_visits = h[1]; out->tri_tests = h[2]; out->box_tests = h[3];
     for (int k = 0; k < 9; k++) out->util[k] = h[4 + k];
     out->reserved[0] = h[13]; out->reserved[1] = h[14];
-    for (int k = 0; k < 4; k++) out->shade[k] = h[15 + k];   // instrumented: max node visits / max rays of any single pixel
+    for (int k = 0; k < 4; k++) out->shade[k] = h[15 + k];
+    for (int k = 0; k < 4; k++) out->waves[k] = h[19 + k];   // instrumented: waves, sum / max of their life times, drain time
     // paths = spp * pixels owned by this rank
     uint64_t pixels = 0;
     for (uint32_t t = c->rank; t < c->n_tiles; t += c->world) {
@@ -455,6 +469,14 @@ int srt_get_stats(srt_ctx *c, srt_stats *out) {
         pixels += (uint64_t)w * hgt;
     }
     out->paths = pixels * c->spp;
+    return SRT_OK;
+}
+
+int srt_get_wave_debug(srt_ctx *c, uint32_t *out, size_t n_waves) {
+    if (!c || !out || !c->d_wave_debug || n_waves > c->wave_debug_waves) return fail(c, SRT_ERR_INVALID, "srt_get_wave_debug: no instrumented launch yet / bad size");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipDeviceSynchronize());
+    HIP_TRY(c, hipMemcpy(out, c->d_wave_debug, n_waves * 4 * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return SRT_OK;
 }
 

@@ -44,7 +44,8 @@ struct RenderParams {
     uint32_t *pixel_counter;              // device word, zeroed before the launch: head of the pixel queue
     const uint32_t *tile_order;           // optional: queue slot -> local tile (cost-descending order); null = identity
     uint32_t *tile_cost;                  // probe mode: per local tile, node records visited by its pixels
-    const uint32_t *queue_rows;           // optional: [0] = number of queue rows (device-written by order_tiles_kernel)
+    const uint32_t *queue_rows;           // optional: [0] = number of queue rows, [1] = the largest tile cost (device-written by order_tiles_kernel)
+    const uint32_t *prio_cost;            // optional: the probe's per-tile cost, read by the render launch for its wave priorities
     uint32_t queue_rows_bound;            // host-side upper bound of the row count (= tiles_local without splitting)
     uint32_t waves_per_cu_override;       // 0 = occupancy API
     uint32_t score_shade, score_fringe;   // step-choice weights, 256 / relative step cost (both >= 1)
@@ -55,6 +56,7 @@ struct RenderParams {
     float *tile_out;                      // [group][local tile (tiles_padded of them)][plane of the group][lane]
     uint32_t tile_group_stride;           // floats between two groups = tiles_padded * 3 * 64
     unsigned long long *counters;
+    uint32_t *wave_debug;                 // instrumented build, optional: 4 words per wave (see srt_get_wave_debug)
 };
 
 struct ScatterParams {

@@ -40,6 +40,7 @@ struct LdsUniforms {
     uint32_t lane_limit;
     uint32_t rng[2], tile_out[2], tile_order[2], tile_cost[2], pixel_counter[2];
     uint32_t tile_group_stride;
+    uint32_t prio_cost[2], prio_full;      // per-tile probe cost (read-only in the render launch) and cost_max * spp (as float bits)
 };
 static_assert(sizeof(LdsUniforms) <= kLdsUniF4 * 16, "uniform block too large");
 typedef __attribute__((address_space(3))) LdsUniforms lds_uniforms;
@@ -59,6 +60,14 @@ constexpr size_t kLdsBudget = 160 * 1024;
 #endif
 #ifndef SRT_ASM_BURST
 #define SRT_ASM_BURST 2      /* 0: C++ bursts, 1: assembly bursts, 2: assembly decision + bursts */
+#endif
+#ifndef SRT_PRIO_MODE
+#define SRT_PRIO_MODE 1      /* wave priorities by remaining chain length (least slack first), see render_kernel */
+#endif
+#ifndef SRT_PRIO_T1
+#define SRT_PRIO_T1 256      /* tiers: remaining chain > T / 1024 of the longest chain of the launch */
+#define SRT_PRIO_T2 64
+#define SRT_PRIO_T3 16
 #endif
 #ifndef SRT_INNER_BURST_L2
 #define SRT_INNER_BURST_L2 4
@@ -180,6 +189,8 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
         split_ptr(P.rng, U->rng); split_ptr(P.tile_out, U->tile_out); split_ptr(P.tile_order, U->tile_order);
         split_ptr(P.tile_cost, U->tile_cost); split_ptr(P.pixel_counter, U->pixel_counter);
         U->tile_group_stride = P.tile_group_stride;
+        split_ptr(P.prio_cost, U->prio_cost);
+        U->prio_full = __float_as_uint(P.queue_rows && P.prio_cost ? (float)P.queue_rows[1] * (float)P.spp : 0.f);
     }
     for (uint32_t k = threadIdx.x; k < kLdsCmfF4; k += blockDim.x) s_cmf[k] = P.cmf[k];
     for (uint32_t k = threadIdx.x; k < nc; k += blockDim.x) {
@@ -237,6 +248,8 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
     bool parked = false, exclusive = false;
     unsigned long long t_shade = 0, t_inner = 0, t_fringe = 0, t_mark = 0;   // instrumented build: wave cycles per phase
     if (COUNT) t_mark = __builtin_amdgcn_s_memtime();
+    const unsigned long long t_born = t_mark;
+    unsigned long long t_dry = 0;            // instrumented build: when the pixel queue first came back empty for this wave
     uint32_t cur_tile_local = 0, pixel_iters0 = 0;   // probe / instrumented builds
     uint32_t pixel_rays0 = 0, max_pix_iters = 0, max_pix_rays = 0;
     uint32_t w_shade_passes = 0, l_shade = 0, l_cam = 0, w_reject_iters = 0;   // instrumented build: shading-phase occupancy
@@ -374,6 +387,7 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
             }
 
             // ---- S3: pixel switch: all samples of the current pixel done (or no pixel yet) ------------------------
+            const bool switched_any = SRT_PRIO_MODE != 0 && ALL_CACHED && __ballot(!dead && !parked && tv.node < 0 && !have_path && !begin_trav && (!have_pixel || sample == spp)) != 0ull;
             if (!dead && !parked && tv.node < 0 && !have_path && !begin_trav && (!have_pixel || sample == spp)) {
                 if (have_pixel && PROBE) {
                     // cost of this pixel = node records it visited (+1 so that empty pixels still sort after real ones)
@@ -417,7 +431,7 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
                     if ((int)lane == leader) base = atomicAdd(join_ptr<uint32_t>(U->pixel_counter[0], U->pixel_counter[1]), (uint32_t)__popcll(m));
                     base = (uint32_t)__shfl((int)base, leader, 64);
                     const uint32_t pix = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                    if (pix >= U->n_rows * 64u) { dead = true; searching = false; }
+                    if (pix >= U->n_rows * 64u) { dead = true; searching = false; if (COUNT && t_dry == 0) t_dry = __builtin_amdgcn_s_memtime(); }
                     else {
                         // queue row = tile | part << 22 | s << 28: the row covers lanes [part * (64 >> s), (part + 1) * (64 >> s))
                         // of the tile (s = 0: the whole tile).  Cost-descending order, see order_tiles_kernel.
@@ -469,6 +483,33 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
                 // load result a FRINGE visit uses -- all six record loads before touching the first one.
                 __builtin_amdgcn_s_waitcnt(0x0070);      // vmcnt(0) lgkmcnt(0)
             }
+
+#if SRT_PRIO_MODE
+            // ---- wave priority: least slack first ----------------------------------------------------------------------------
+            // The SIMD's arbiter prefers OLDER waves (srt_calib: with four resident waves two run at their single-wave speed and
+            // two starve) and persistent waves keep their age order for the whole launch: which pixels run fast is an accident of
+            // the dispatch order, and the starved wave of every SIMD is left alone with its last pixels when the others have gone
+            // (a lone wave reaches half of the SIMD's issue rate at best; tools/wave_tail.py).  Here a wave sets its own priority
+            // from the longest chain it still holds: the probe's cost of a lane's tile x the samples the lane still has to draw,
+            // against the same product for the most expensive tile of the launch -- more than 1/4, 1/16, 1/64 of it: priority 3, 2,
+            // 1 (sweep: profiles/r03/experiments/wave_priorities.txt).  Lagging waves rise, waves that only hold cheap or nearly
+            // finished pixels fall: expensive chains get the issue slots, and the waves of a SIMD finish together.  Re-evaluated
+            // whenever a lane of the wave switched pixel.  Not for trees served by L2 (memory-bound: -1.5 % there).
+            // Scheduling only: results do not depend on it.
+            if (!PROBE && ALL_CACHED && switched_any) {
+                float rem = 0.f;
+                const uint32_t *tc = join_ptr<const uint32_t>(U->prio_cost[0], U->prio_cost[1]);
+                if (tc && have_pixel && !dead) rem = (float)tc[out_slot / (uint32_t)(kGroupPlanes * kTileLanes)] * (float)(spp - sample);
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) rem = fmaxf(rem, __shfl_xor(rem, off, 64));
+                const float full = __uint_as_float(U->prio_full);
+                const uint32_t pr = (uint32_t)__builtin_amdgcn_readfirstlane((int)((rem > (SRT_PRIO_T1 / 1024.0f) * full ? 1u : 0u) + (rem > (SRT_PRIO_T2 / 1024.0f) * full ? 1u : 0u) + (rem > (SRT_PRIO_T3 / 1024.0f) * full ? 1u : 0u)));
+                if (pr == 0u) __builtin_amdgcn_s_setprio(0);
+                else if (pr == 1u) __builtin_amdgcn_s_setprio(1);
+                else if (pr == 2u) __builtin_amdgcn_s_setprio(2);
+                else __builtin_amdgcn_s_setprio(3);
+            }
+#endif
 
             // ---- S4: new camera ray: renderer::get_ray (rendering.cu:66-87) ----------------------------------------
             if (COUNT) l_cam += (uint32_t)__popcll(__ballot(!dead && tv.node < 0 && !have_path && !begin_trav && have_pixel && sample < spp));
@@ -612,6 +653,14 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
                 atomicAdd(&P.counters[9], (unsigned long long)ts.l_inner);
                 atomicAdd(&P.counters[10], t_shade);
             }
+            // the first time any lane of the wave found the queue empty (units of 256 cycles since the wave's birth)
+            const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+            uint32_t dry_first = t_dry ? (uint32_t)((t_dry - t_born) >> 8) : 0xffffffffu;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) dry_first = min(dry_first, (uint32_t)__shfl_xor((int)dry_first, off, 64));
+            uint32_t wave_max_pix_rays = max_pix_rays;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) wave_max_pix_rays = max(wave_max_pix_rays, (uint32_t)__shfl_xor((int)wave_max_pix_rays, off, 64));
             atomicMax(&P.counters[13], (unsigned long long)max_pix_iters);
             atomicMax(&P.counters[14], (unsigned long long)max_pix_rays);
             if (lane == 0) {
@@ -621,6 +670,15 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
                 atomicAdd(&P.counters[16], (unsigned long long)l_shade);
                 atomicAdd(&P.counters[17], (unsigned long long)l_cam);
                 atomicAdd(&P.counters[18], (unsigned long long)w_reject_iters);
+                if (P.wave_debug) {
+                    // per wave: end of life and of the queue (units of 256 cycles since birth), rays, the most expensive pixel (rays)
+                    uint32_t *w = P.wave_debug + 4u * (blockIdx.x * (blockDim.x >> 6) + wave);
+                    w[0] = (uint32_t)((t_end - t_born) >> 8); w[1] = dry_first; w[2] = r; w[3] = wave_max_pix_rays;
+                }
+                atomicAdd(&P.counters[19], 1ull);
+                atomicAdd(&P.counters[20], t_end - t_born);
+                atomicMax(&P.counters[21], t_end - t_born);
+                atomicAdd(&P.counters[22], dry_first != 0xffffffffu ? (t_end - t_born) - ((unsigned long long)dry_first << 8) : 0ull);
             }
         }
     }
@@ -716,6 +774,7 @@ __global__ __launch_bounds__(1024) void order_tiles_kernel(const uint32_t *__res
         uint32_t acc = 0;
         for (uint32_t b = 0; b < 1024u; b++) { const uint32_t c = s_scan[b]; s_scan[b] = acc; acc += c; }
         queue_info[0] = acc;
+        queue_info[1] = s_max;      // the most expensive tile's probe cost (render_kernel's wave priorities)
     }
     __syncthreads();
     uint32_t at = s_scan[t];

@@ -117,8 +117,17 @@ class Renderer:
         d = {k: getattr(st, k) for k in ("rays", "paths", "node_visits", "tri_tests", "box_tests")}
         d["util"] = list(st.util)
         d["shade"] = list(st.shade)
+        d["waves"] = list(st.waves)
         d["max_pixel_node_visits"], d["max_pixel_rays"] = st.reserved[0], st.reserved[1]
         return d
+
+    def wave_debug(self):
+        """per persistent wave of the last INSTRUMENTED launch: [life, queue-dry time (256-cycle units), rays, rays of its most expensive pixel]"""
+        n = int(self.stats()["waves"][0])
+        out = np.zeros((n, 4), np.uint32)
+        if n:
+            self._ck(B.lib().srt_get_wave_debug(self._h, out.ctypes.data_as(C.POINTER(C.c_uint32)), n))
+        return out
 
     def last_kernel_ms(self):
         ms = C.c_float()

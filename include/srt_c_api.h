@@ -89,6 +89,10 @@ typedef struct {
     /* instrumented kernel only: [0] shading passes (wave level), [1] lanes that shaded a finished query in them,
      * [2] lanes that generated a camera ray, [3] wave-level iterations of the unit-sphere rejection loop */
     uint64_t shade[4];
+    /* instrumented kernel only, the tail of a launch: [0] waves, [1] sum of their life times (shader cycles from the start of
+     * their state machine to their exit), [2] the longest life, [3] sum of the cycles waves lived on after the pixel queue had
+     * run dry for them (drain time: lanes finishing their last pixels).  mean / max life = [1] / ([0] * [2]). */
+    uint64_t waves[4];
 } srt_stats;
 
 typedef struct srt_scene srt_scene;   /* host-side flattened scene (replaces scene_manager's device heap) */
@@ -216,6 +220,10 @@ SRT_API int srt_read_fb_aux(srt_ctx *ctx, int which, float *p0, float *p1, float
 SRT_API int srt_get_tile_costs(srt_ctx *ctx, uint32_t *out, size_t n);
 SRT_API int srt_get_stats(srt_ctx *ctx, srt_stats *out);       /* counters of the last srt_render_chunk */
 SRT_API int srt_set_count_traversal(srt_ctx *ctx, int on);     /* 1: instrumented kernel also counts V / T */
+/* Instrumented launches only (diagnostics of the tail of a launch): 4 words per persistent wave -- [0] its life time and [1] the
+ * moment the pixel queue first came back empty for it (both in units of 256 shader cycles since the wave started; [1] = 2^32-1 if
+ * never), [2] its closest-hit queries, [3] the queries of its most expensive pixel.  n_waves <= srt_stats.waves[0]. */
+SRT_API int srt_get_wave_debug(srt_ctx *ctx, uint32_t *out, size_t n_waves);
 /* Kernel-only time of the last srt_render_chunk in ms, measured with HIP events on its stream. */
 SRT_API int srt_last_kernel_ms(srt_ctx *ctx, float *ms);
 /* Closest-hit query for explicit rays (bvh::hit, bvh/bvh.cu:98-166) -- KAT entry point.

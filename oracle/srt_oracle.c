@@ -848,11 +848,11 @@ typedef struct {
     orc_stats stats;
 } render_job;
 
-/* rendering.cu:151-235 for one block of tx*ty lanes */
-static void render_block(render_job *J, uint32_t block_idx) {
+/* rendering.cu:151-235 for one row (threadIdx.y = tyi) of one block of tx*ty lanes.  Pixels are independent (own RNG stream),
+ * so the unit of work a host thread takes is a block ROW: a handful of blocks at thousands of spp still keeps every thread busy. */
+static void render_block_row(render_job *J, uint32_t block_idx, uint32_t tyi) {
     const uint32_t block_size = J->tx * J->ty;
     const uint32_t gbx = block_idx % J->bx, gby = block_idx / J->bx;
-    for (uint32_t tyi = 0; tyi < J->ty; tyi++)
         for (uint32_t txi = 0; txi < J->tx; txi++) {
             uint32_t i = txi + gbx * J->tx;
             uint32_t j = tyi + gby * J->ty;
@@ -888,10 +888,10 @@ static void *render_worker(void *arg) {
     render_job local = *(render_job *)arg;
     render_job *J = &local;
     for (;;) {
-        uint32_t k = __sync_fetch_and_add(J->next_block, 1u);
-        uint32_t b = J->block_lo + k * J->block_stride;
+        uint32_t k = __sync_fetch_and_add(J->next_block, 1u);      /* work item k = row k % ty of the (k / ty)-th selected block */
+        uint32_t b = J->block_lo + (k / J->ty) * J->block_stride;
         if (b >= J->block_hi) break;
-        render_block(J, b);
+        render_block_row(J, b, k % J->ty);
     }
     ((render_job *)arg)->stats = local.stats;
     return NULL;

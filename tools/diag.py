@@ -32,6 +32,7 @@ for count in (True, False):
                    trav_simd_util=st["node_visits"] / (64.0 * u[0]), alive_frac=u[1] / (64.0 * u[0]), trav_over_alive=st["node_visits"] / max(u[1], 1), nan_ray_frac=u[2] / st["rays"], fringe_steps_frac=u[3] / max(u[0], 1), fringe_lane_util=u[4] / (64.0 * max(u[3], 1)), inner_lane_util=u[5] / (64.0 * max(u[0] - u[3], 1)), cycles_shade_inner_fringe=[u[6] / max(u[6] + u[7] + u[8], 1), u[7] / max(u[6] + u[7] + u[8], 1), u[8] / max(u[6] + u[7] + u[8], 1)],
                    cyc_per_inner_step=u[7] / max(u[0] - u[3], 1), cyc_per_fringe_step=u[8] / max(u[3], 1), max_pixel_node_visits=st["max_pixel_node_visits"], max_pixel_rays=st["max_pixel_rays"], mean_pixel_node_visits=st["node_visits"] / (a.width * a.height / a.world), ms_instrumented=best,
                    shade_passes=st["shade"][0], lanes_shaded_per_pass=st["shade"][1] / max(st["shade"][0], 1), camera_rays_per_pass=st["shade"][2] / max(st["shade"][0], 1),
+                   wave_life_mean_over_max=(st["waves"][1] / max(st["waves"][0], 1)) / max(st["waves"][2], 1), wave_drain_share=st["waves"][3] / max(st["waves"][1], 1), wave_life_max_cycles=st["waves"][2],
                    cyc_per_shade_pass=u[6] / max(st["shade"][0], 1), shade_raw=list(st["shade"]), shade_cycles=u[6], inner_steps=u[0] - u[3], fringe_steps=u[3])
     else:
         res.update(ms=best, mray_s=st["rays"] / best / 1e3)
