@@ -6,7 +6,7 @@ TAG=${1:-vX}
 OUT="$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p "$OUT"
-[ "${2:-}" = "pmc-only" ] || timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err" || { echo "trace run failed"; tail -5 "$OUT/bench.err"; exit 1; }
+[ "${2:-}" = "pmc-only" ] || timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python bench.py --no-cpu-baseline > "$OUT/bench.json" 2> "$OUT/bench.err" || { echo "trace run failed"; tail -5 "$OUT/bench.err"; exit 1; }
 [ "${2:-}" = "pmc-only" ] || cat "$OUT/bench.json"
 [ "${2:-}" = "pmc-only" ] || find "$OUT/trace" -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats.csv" \;
 [ "${2:-}" = "pmc-only" ] || cat "$OUT/kernel_stats.csv"
