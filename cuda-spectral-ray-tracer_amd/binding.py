@@ -70,6 +70,7 @@ PROTOTYPES = {
     "srt_scene_get_background": (_i, [_vp, _fp]),
     "srt_scene_get_tri_records": (_i, [_vp, _fp]),
     "srt_material_bake": (_i, [C.POINTER(Material)]),
+    "srt_set_reference_quirks": (_i, [_i]),
     "srt_bake_sigmoid_spectrum": (_i, [_fp, _f, _i, _fp]),
     "srt_fit_sigmoid_coeffs": (_i, [_fp, _fp]),
     "srt_color_tables": (_i, [_fp, _fp]),

@@ -537,10 +537,18 @@ static void bake_sigmoid(const float c[3], float scale, bool times_d65, float *o
         lambda += step;
     }
 }
+// Reference quirks that live in SCENE CONSTRUCTION (inputs of the path, not the path): Q1 the Sellmeier constructor copies B into C
+// (materials/material.cuh:66-67: NaN / sub-unity indices over most of the spectrum), Q2 grey colours return their sigmoid
+// coefficient in the slot the evaluator reads as the QUADRATIC term (color_to_spectrum.cuh:118-120 vs :153-156: albedo 0.73 bakes
+// to 1.0, < 0.5 to 0).  Default on -- every parity statement is about the reference as written; srt_set_reference_quirks(0)
+// (srt_render --physically-correct) builds and bakes what the author evidently meant.  Not parity-checked.
+static int g_reference_quirks = 1;
 static bool grey_coeffs(const float rgb[3], float c[3]) {   // :118-120
     if (!(rgb[0] == rgb[1] && rgb[1] == rgb[2])) return false;
     const float r = rgb[0];
-    c[0] = 0.f; c[1] = 0.f; c[2] = (r - .5f) / sqrtf(r * (1 - r));
+    const float k = (r - .5f) / sqrtf(r * (1 - r));
+    c[0] = 0.f; c[1] = 0.f; c[2] = 0.f;
+    c[g_reference_quirks ? 2 : 0] = k;      // quirk Q2: the constant lands in the lambda^2 slot
     return true;
 }
 
@@ -666,7 +674,10 @@ static srt_material make_material(uint32_t type, float r, float g, float b, floa
     m.col[0] = r; m.col[1] = g; m.col[2] = b;
     m.reflection_fuzz = fuzz; m.material_type = type; m.emission_power = power;
     if (B3) {
-        for (int i = 0; i < 3; i++) { m.sellmeier_B[i] = B3[i]; m.sellmeier_C[i] = B3[i]; }   // C := B, material.cuh:66-67 (Q1)
+        static const float kFlintC[3] = {0.00997743871f, 0.0470450767f, 111.886764f};      // refraction/sellmeier.cuh:15
+        static const float kBK7C[3] = {6.00069867e-3f, 2.00179144e-2f, 1.03560653e2f};     // refraction/sellmeier.cuh:7
+        const float *C3 = B3[0] > 1.2f ? kFlintC : kBK7C;
+        for (int i = 0; i < 3; i++) { m.sellmeier_B[i] = B3[i]; m.sellmeier_C[i] = g_reference_quirks ? B3[i] : C3[i]; }   // C := B, material.cuh:66-67 (Q1)
     } else {
         m.sellmeier_B[0] = 1.0f;   // material(col, fuzz, ir = 1, power, type), material.cuh:49-61
     }
@@ -1124,6 +1135,7 @@ int srt_bake_sigmoid_spectrum(const float coeffs[3], float scale, int times_d65,
     bake_sigmoid(coeffs, scale, times_d65 != 0, out);
     return SRT_OK;
 }
+int srt_set_reference_quirks(int on) { const int was = g_reference_quirks; g_reference_quirks = on ? 1 : 0; return was; }
 int srt_material_bake(srt_material *m) {
     if (!m) { set_global_error("bake: null material"); return SRT_ERR_INVALID; }
     float c[3];

@@ -2,7 +2,7 @@
 // (SURVEY 8(f) rows f2/f3): main.cpp:135-167, io/params.h:236-304, _log_/log_context.cpp:5-65,
 // io/save_image.cpp:8-20 + image/image.cpp:3-18 (CImg replaced by a 30-line BMP writer).
 //
-//   srt_render -s 1 -xr 600 -ar 16/9 -ns 500 -bl 10 -xc 0 -yc 0 -t "my title" --save --do-log [--gpu N | --gpus N] [--sah]
+//   srt_render -s 1 -xr 600 -ar 16/9 -ns 500 -bl 10 -xc 0 -yc 0 -t "my title" --save --do-log [--gpu N | --gpus N] [--sah] [--physically-correct]
 //
 // Scene ids 0/1/2 are the reference's CORNELL/PRISM/TRIS (io/params.h:15-19); 100/101 are this build's
 // synthetic benchmark scenes.  There is no window (--no-show is accepted and is the only mode).
@@ -73,6 +73,8 @@ bool parseArgs(int argc, char **argv, parameters &p) {   // params.h:236-304
             else if (!is_last && arg == "--gpu") p.gpu = std::stoi(argv[++i]);
             else if (!is_last && arg == "--gpus") p.gpus = std::max(1, std::stoi(argv[++i]));
             else if (arg == "--sah") p.sah = true;
+            else if (arg == "--physically-correct") srt_set_reference_quirks(0);      // Q1 / Q2 off (not parity-checked)
+            else if (arg == "--reference-quirks") srt_set_reference_quirks(1);        // the default
             else if (arg == "--do-log") p.do_log = true;
             else if (arg == "--no-show") p.show_render = false;
             else if (arg == "--save") p.do_save = true;

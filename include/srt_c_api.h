@@ -131,6 +131,12 @@ SRT_API int srt_scene_get_tri_records(const srt_scene *s, float *out);
 /* material::compute_spectral_distr (materials/material.cuh:71-84) for table-free colours (grey, white,
  * light, glass); SRT_ERR_UNSUPPORTED for non-grey sRGB (utils/srgb_to_spectrum.cu is absent upstream). */
 SRT_API int srt_material_bake(srt_material *m);
+/* Quirks of the reference's scene construction (Sellmeier C := B, materials/material.cuh:66-67; Q2: a grey colour's
+ * sigmoid coefficient lands in the quadratic slot, color_to_spectrum.cuh:118-120): on (1, default) reproduces the reference as
+ * written -- every parity statement refers to that --, 0 builds / bakes what was evidently meant (real Sellmeier C coefficients,
+ * grey albedo g -> constant spectrum g).  Process-wide, affects srt_scene_builtin and srt_material_bake / srt_background_spectrum
+ * calls made afterwards; returns the previous setting.  The render path itself has no switch. */
+SRT_API int srt_set_reference_quirks(int on);
 /* dev_srgb_to_spectrum / dev_srgb_to_illuminance_spectrum evaluated from explicit sigmoid coefficients
  * (color/color_to_spectrum.cuh:173-186,204-219): value = [scale * D65n(l)] * sigmoid(c[2] l^2 + c[1] l + c[0]). */
 SRT_API int srt_bake_sigmoid_spectrum(const float coeffs[3], float scale, int times_d65, float out[SRT_N_CIE_SAMPLES]);

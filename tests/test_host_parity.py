@@ -178,3 +178,35 @@ def test_order_children_for_a_viewpoint(srt, orc):
     assert not np.array_equal(l0, l1)                                                      # something really moved
     osc = orc.OracleScene(scene.triangles(), scene.materials(), scene.background())
     assert osc.set_bvh(l1, r1, p1, 0) == 1
+
+
+def test_reference_quirks_switch(srt, orc):
+    """SURVEY section 7's opt-out (`--physically-correct`): quirks Q1 (Sellmeier C := B) and Q2 (grey coefficient in the quadratic slot)
+    live in scene construction; the switch is process-wide, default ON (every parity statement is about the reference as written) and
+    NOT parity-checked when off.  On: flint 'glass' has NaN / absurd indices and albedo 0.73 bakes to 1.0 (the survey's probes); off:
+    n(lambda) in 1.6 .. 1.7 and albedo 0.73 -> 0.73."""
+    import ctypes as C
+    B = srt.binding
+    L = B.lib()
+    fp = C.POINTER(C.c_float)
+
+    def probe():
+        scene = srt.Scene.builtin(srt.SCENE_PRISM, 0)
+        glass = [m for m in scene.materials() if m.material_type == B.MAT_DIELECTRIC][0]
+        b = np.array(list(glass.sellmeier_B), np.float32); c = np.array(list(glass.sellmeier_C), np.float32)
+        n = np.array([orc.lib().orc_sellmeier_index(b.ctypes.data_as(fp), c.ctypes.data_as(fp), float(lam)) for lam in (400.0, 550.0, 700.0)])
+        m = B.Material()
+        m.col[:] = (0.73, 0.73, 0.73); m.material_type = B.MAT_LAMBERTIAN
+        B.check(L.srt_material_bake(C.byref(m)))
+        return n, np.array(list(m.spectral_distribution), np.float32)
+    assert L.srt_set_reference_quirks(1) in (0, 1)
+    n_on, sd_on = probe()
+    assert np.isnan(n_on).any() or n_on.min() < 1.0                 # Q1: NaN or n < 1 over most of the spectrum
+    assert np.all(sd_on == 1.0)                                     # Q2: 0.73 saturates to 1.0
+    assert L.srt_set_reference_quirks(0) == 1
+    try:
+        n_off, sd_off = probe()
+        assert np.all((n_off > 1.6) & (n_off < 1.7)) and n_off[0] > n_off[2]      # flint glass, normal dispersion
+        assert np.allclose(sd_off, 0.73, atol=1e-6)
+    finally:
+        assert L.srt_set_reference_quirks(1) == 0
