@@ -1,5 +1,6 @@
 // srt_capi.cpp -- device half of the C-ABI: one srt_ctx = one GPU's renderer
 // (replaces `renderer`, rendering/rendering.cuh:39-155, and the device half of render_manager::step).
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 #include <string.h>
@@ -72,6 +73,28 @@ struct srt_ctx {
 };
 
 namespace {
+
+// Optional roctx ranges around the phases of srt_render_chunk (cost probe, queue build, render launch): they show up in
+// rocprofv3 --marker-trace timelines next to the kernels.  libroctx64 is looked up once with dlopen; absent library = no ranges.
+struct Roctx {
+    int (*push)(const char *) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx() {
+        for (const char *n : {"libroctx64.so.4", "libroctx64.so", "/opt/rocm/lib/libroctx64.so.4"}) {
+            if (void *h = dlopen(n, RTLD_NOW | RTLD_LOCAL)) {
+                push = (int (*)(const char *))dlsym(h, "roctxRangePushA");
+                pop = (int (*)())dlsym(h, "roctxRangePop");
+                if (push && pop) return;
+                push = nullptr; pop = nullptr;
+            }
+        }
+    }
+};
+struct RoctxRange {
+    static Roctx &api() { static Roctx r; return r; }
+    explicit RoctxRange(const char *name) { if (api().push) api().push(name); }
+    ~RoctxRange() { if (api().pop) api().pop(); }
+};
 
 int fail(srt_ctx *ctx, int code, const std::string &msg) {
     if (ctx) ctx->err = msg;
@@ -317,12 +340,13 @@ int srt_render_chunk(srt_ctx *c, uint32_t width, uint32_t height, uint32_t offx,
         HIP_TRY(c, hipMemsetAsync(c->d_tile_cost, 0, c->tiles_local * sizeof(uint32_t), st));
         RenderParams pp = p;
         pp.spp = c->probe_spp; pp.tile_cost = c->d_tile_cost;
+        RoctxRange range_probe("srt cost probe + pixel queue");
         HIP_TRY(c, launch_render(pp, (uint32_t)c->n_cu, 2, st));
         HIP_TRY(c, launch_order_tiles(c->d_tile_cost, sorted, rows, c->tiles_local, (uint32_t)c->n_cu * (uint32_t)plan.waves_per_cu, c->split_load_pct, queue_info, st));   // device-side, no host sync
         HIP_TRY(c, hipMemsetAsync(c->d_counters + kCounters, 0, sizeof(unsigned long long), st));   // rewind the queue head
         p.tile_order = rows;
         p.queue_rows = queue_info;
-        p.prio_cost = c->d_tile_cost;
+        p.prio_cost = c->d_tile_cost;      // wave priorities of the render launch (render_kernel, LDS-resident trees)
         if (c->split_load_pct) p.queue_rows_bound = (uint32_t)std::min<uint64_t>((uint64_t)c->tiles_local * 64, 0x7fffffffull);
     }
     if (c->count_traversal) {
@@ -335,6 +359,7 @@ int srt_render_chunk(srt_ctx *c, uint32_t width, uint32_t height, uint32_t offx,
         HIP_TRY(c, hipMemsetAsync(c->d_wave_debug, 0, (size_t)c->wave_debug_waves * 4 * sizeof(uint32_t), st));
         p.wave_debug = c->d_wave_debug;
     }
+    RoctxRange range_render("srt render_kernel");
     HIP_TRY(c, hipEventRecord(c->ev0, st));     // ev0..ev1 bracket the render kernel alone (roofline.achieved)
     HIP_TRY(c, launch_render(p, (uint32_t)c->n_cu, c->count_traversal ? 1 : 0, st));
     HIP_TRY(c, hipEventRecord(c->ev1, st));

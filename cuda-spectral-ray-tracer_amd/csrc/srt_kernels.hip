@@ -494,7 +494,8 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
             // against the same product for the most expensive tile of the launch -- more than 1/4, 1/16, 1/64 of it: priority 3, 2,
             // 1 (sweep: profiles/r03/experiments/wave_priorities.txt).  Lagging waves rise, waves that only hold cheap or nearly
             // finished pixels fall: expensive chains get the issue slots, and the waves of a SIMD finish together.  Re-evaluated
-            // whenever a lane of the wave switched pixel.  Not for trees served by L2 (memory-bound: -1.5 % there).
+            // whenever a lane of the wave switched pixel.  Not compiled into the variant for trees served by L2: that one is
+            // memory-bound, the priorities cost it 1.5-2 % on a full frame and return 2 % on one rank's share of an 8-rank frame.
             // Scheduling only: results do not depend on it.
             if (!PROBE && ALL_CACHED && switched_any) {
                 float rem = 0.f;

@@ -150,6 +150,26 @@ def test_image_bit_exact(srt, gpu, orc, sid, mode, W, H, spp, depth, count_trave
         assert np.array_equal(out["rowmajor"][c], want)
 
 
+def test_reordered_tree_for_another_viewpoint_bit_exact(srt, gpu, orc):
+    """srt_scene_order_children: the SAH tree re-ordered for a camera that is NOT the scene's default one (nearer child first at
+    every node), rendered from that camera by both kernel builds == the oracle walking the same re-ordered tree; and fewer node
+    visits than the default-camera order gives from there (the point of the call)."""
+    scene = srt.Scene.builtin(srt.SCENE_RANDOM_SPHERES, 0).build_bvh(srt.BVH_SAH)
+    W, H, spp, depth = 96, 54, 6, 16
+    eye = (-9.0, 2.5, -6.0)
+    cam = srt.camera_init(W, H, 35.0, eye, (0.0, 0.5, 0.0))
+    base = srt.render_image(scene, cam, W, H, spp, depth, renderer=gpu, count_traversal=True)
+    scene.order_children(eye)
+    ref = oracle_scene_for(orc, scene, 1).render(cam, W, H, spp, depth)
+    for counted in (True, False):
+        out = srt.render_image(scene, cam, W, H, spp, depth, renderer=gpu, count_traversal=counted)
+        assert_planes_equal(out["xyz"], ref["xyz"], "re-ordered tree XYZ, counted=%s" % counted)
+        assert_planes_equal(out["fb"], ref["fb"], "re-ordered tree fb, counted=%s" % counted)
+        assert out["stats"]["rays"] == ref["stats"]["rays"]
+        if counted:
+            assert out["stats"]["node_visits"] < base["stats"]["node_visits"]
+
+
 def test_trace_rays_matches_oracle(srt, gpu, orc):
     """bvh::hit for explicit rays incl. degenerate ones (zero / NaN / axis-parallel directions, origins on surfaces)."""
     scene = srt.Scene.builtin(srt.SCENE_CORNELL).build_bvh(srt.BVH_REFERENCE, 1984)
