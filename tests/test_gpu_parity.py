@@ -385,11 +385,12 @@ def test_full_frame_full_spp_bit_exact(srt, gpu, orc):
     rays) against the oracle, bit for bit.  Opt-in (SRT_LONG=1): ~7 minutes of oracle time on 256 host threads.  Result of
     the last run: profiles/r02/full_frame_parity.txt."""
     import sys, time
-    cfg = os.environ.get("SRT_LONG_CFG", "3")          # 3: the headline frame; 2: cfg 2's frame; 5: cfg 5's scene at 3840x2160, 64 spp
+    cfg = os.environ.get("SRT_LONG_CFG", "3")          # 3: the headline frame; 2: cfg 2's frame; 4: cfg 4's frame (PRISM); 5: cfg 5's scene at 3840x2160, 64 spp
     sid, W, H, spp = {"2": (srt.SCENE_RANDOM_SPHERES, 1280, 720, 256), "3": (srt.SCENE_RANDOM_SPHERES, 1920, 1080, 1024),
-                      "5": (srt.SCENE_MESH100K, 3840, 2160, 64)}[cfg]
+                      "4": (srt.SCENE_PRISM, 1920, 1080, 2048), "5": (srt.SCENE_MESH100K, 3840, 2160, 64)}[cfg]
     spp, depth = int(os.environ.get("SRT_LONG_SPP", str(spp))), 16
-    scene = srt.Scene.builtin(sid, 0).build_bvh(srt.BVH_SAH)
+    bvh_mode = srt.BVH_REFERENCE if cfg == "4" else srt.BVH_SAH      # (the reference's scene on the reference builder's tree)
+    scene = srt.Scene.builtin(sid, 0).build_bvh(bvh_mode, 1984)
     cam = scene.default_camera(W, H)
     gpu.upload_scene(scene); gpu.set_camera(cam); gpu.set_partition(0, 1)
     gpu.init_device_params(W, H, spp, depth, 1984)
@@ -398,7 +399,7 @@ def test_full_frame_full_spp_bit_exact(srt, gpu, orc):
     gpu.scatter_tiles()
     fb, xyz = gpu.read_fb(), gpu.read_fb_aux(2)
     n_blocks = gpu.geom["bx"] * gpu.geom["by"]
-    osc = oracle_scene_for(orc, scene, 1)
+    osc = oracle_scene_for(orc, scene, 0 if cfg == "4" else 1)
     threads = os.cpu_count() or 1
     slices, differing, checked, t0 = 16, 0, 0, time.time()
     threads = int(os.environ.get("SRT_LONG_THREADS", str(threads)))
