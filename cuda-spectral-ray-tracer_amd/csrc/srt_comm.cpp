@@ -53,32 +53,39 @@ RcclApi &rccl() {
         // (no fall-backs: also how the CPU suite tests the "RCCL missing" path).
         const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
         std::string first_error;
-        auto try_open = [&](const char *n, int flags) {
+        // a candidate is accepted only if it exports everything this file calls (ncclGather is an RCCL extension: a copy the
+        // host process carries may be older than the system's)
+        auto accept = [&](void *h, bool preloaded) {
+            if (!h || api.handle) { return; }
+            bool ok = true;
+            auto sym = [&](const char *name) { void *p = dlsym(h, name); if (!p) { ok = false; if (first_error.empty()) first_error = std::string("RCCL symbol missing: ") + name; } return p; };
+            RcclApi cand;
+            cand.GetUniqueId = (decltype(cand.GetUniqueId))sym("ncclGetUniqueId");
+            cand.CommInitRank = (decltype(cand.CommInitRank))sym("ncclCommInitRank");
+            cand.CommInitAll = (decltype(cand.CommInitAll))sym("ncclCommInitAll");
+            cand.CommDestroy = (decltype(cand.CommDestroy))sym("ncclCommDestroy");
+            cand.Gather = (decltype(cand.Gather))sym("ncclGather");
+            cand.GroupStart = (decltype(cand.GroupStart))sym("ncclGroupStart");
+            cand.GroupEnd = (decltype(cand.GroupEnd))sym("ncclGroupEnd");
+            cand.GetErrorString = (decltype(cand.GetErrorString))sym("ncclGetErrorString");
+            if (!ok) { dlclose(h); return; }
+            cand.handle = h; cand.preloaded = preloaded;
+            api = cand;
+        };
+        auto try_open = [&](const char *n, int flags, bool preloaded) {
             if (api.handle) return;
             (void)dlerror();
-            api.handle = dlopen(n, flags);
-            if (!api.handle && first_error.empty()) { const char *e = dlerror(); first_error = e ? e : (std::string(n) + " not found"); }
+            void *h = dlopen(n, flags);
+            if (!h && !preloaded && first_error.empty()) { const char *e = dlerror(); first_error = e ? e : (std::string(n) + " not found"); }
+            accept(h, preloaded);
         };
         if (const char *forced = getenv("SRT_RCCL_LIB")) {
-            try_open(forced, RTLD_NOW | RTLD_LOCAL);
+            try_open(forced, RTLD_NOW | RTLD_LOCAL, false);
         } else {
-            for (const char *n : names) try_open(n, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
-            api.preloaded = api.handle != nullptr;
-            first_error.clear();      // "not already mapped" is not an error
-            for (const char *n : names) try_open(n, RTLD_NOW | RTLD_LOCAL);
+            for (const char *n : names) try_open(n, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD, true);      // (RTLD_NOLOAD: only an image that is already mapped)
+            for (const char *n : names) try_open(n, RTLD_NOW | RTLD_LOCAL, false);
         }
-        if (!api.handle) { api.error = "cannot load RCCL: " + (first_error.empty() ? std::string("librccl.so.1 not found") : first_error); return; }
-        bool ok = true;
-        auto sym = [&](const char *name) { void *p = dlsym(api.handle, name); if (!p) { ok = false; api.error = std::string("RCCL symbol missing: ") + name; } return p; };
-        api.GetUniqueId = (decltype(api.GetUniqueId))sym("ncclGetUniqueId");
-        api.CommInitRank = (decltype(api.CommInitRank))sym("ncclCommInitRank");
-        api.CommInitAll = (decltype(api.CommInitAll))sym("ncclCommInitAll");
-        api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy");
-        api.Gather = (decltype(api.Gather))sym("ncclGather");
-        api.GroupStart = (decltype(api.GroupStart))sym("ncclGroupStart");
-        api.GroupEnd = (decltype(api.GroupEnd))sym("ncclGroupEnd");
-        api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
-        if (!ok) { dlclose(api.handle); api.handle = nullptr; }
+        if (!api.handle) api.error = "cannot load RCCL: " + (first_error.empty() ? std::string("librccl.so.1 not found") : first_error);
     });
     return api;
 }
