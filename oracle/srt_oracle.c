@@ -12,12 +12,12 @@
  * -ffp-contract=off, no fast-math).
  *
  * PARITY PINNING STATUS ("partially pinned"):
- *   - The reference is CUDA-only (every hot function is __device__, needs <curand_kernel.h>
+ *   - The reference's render path is CUDA-only (every hot function is __device__, needs <curand_kernel.h>
  *     and the CUDA runtime headers).  Those headers do not exist in this image and the build
- *     rules forbid writing stand-ins for them, so the reference is UNBUILDABLE here and no
- *     oracle/_ref exists.  The reference ships no tests, golden vectors or fixtures.
- *   - Three translation units of the reference DO compile unmodified with this image's hipcc (-x hip): utils/cie_const.cu,
- *     utils/color_const.cu (constant tables) -- oracle/Makefile's `ref` target builds them from where they lie into
+ *     rules forbid writing stand-ins for them, so that path is UNBUILDABLE here.  The reference ships no tests,
+ *     golden vectors or fixtures.
+ *   - Two translation units of the reference hold host data and DO compile unmodified with this image's hipcc (-x hip):
+ *     utils/cie_const.cu, utils/color_const.cu (constant tables) -- oracle/Makefile's `ref` target builds them from where they lie into
  *     oracle/_ref/libref_tables.so, and tests/test_ref_tables.py requires the CIE / D65 rows and the XYZ->sRGB matrix of
  *     this oracle AND of the product to equal the reference's arrays bit for bit.  Nothing else of the reference compiles
  *     without stand-ins.
