@@ -184,7 +184,10 @@ int srt_comm_init_rank(srt_ctx *ctx, const unsigned char id[SRT_COMM_ID_BYTES], 
 int srt_comm_init_all(const int *devices, int n, srt_comm **out) {
     if (!devices || n <= 0 || !out) return cfail(nullptr, SRT_ERR_INVALID, "srt_comm_init_all: bad argument");
     *out = nullptr;
-    for (int i = 0; i < n; i++)
+    // (SRT_COMM_TEST_SAME_DEVICE=1: test hook -- several ranks on one GPU, only meaningful with a transport that allows it:
+    // tests/cpp/mock_rccl.cpp through SRT_RCCL_LIB; RCCL itself refuses a device that appears twice)
+    const char *same = getenv("SRT_COMM_TEST_SAME_DEVICE");
+    for (int i = 0; i < n && !(same && same[0] == '1'); i++)
         for (int j = 0; j < i; j++)
             if (devices[i] == devices[j]) return cfail(nullptr, SRT_ERR_INVALID, "srt_comm_init_all: a device is listed twice (one rank per GPU)");
     RcclApi &R = rccl();

@@ -561,6 +561,52 @@ def test_comm_two_gpus_bit_identical(srt, gpu, orc):
     comm.close()
 
 
+def test_comm_two_and_three_ranks_one_gpu_mock_transport():
+    """The W > 1 branch of srt_render_frame_multi -- gathered-buffer allocation, the grouped gather calls, the scatter from the
+    rank-major buffer (3-plane exchange unit and 9-plane parity unit), exchange timing, per-comm statistics -- on ONE GPU: two / three
+    ranks on device 0 (test hook SRT_COMM_TEST_SAME_DEVICE) over a test transport that implements the eight RCCL entry points with
+    HIP copies (tests/cpp/mock_rccl.cpp, loaded through SRT_RCCL_LIB).  Everything but RCCL itself.  The library caches its RCCL
+    handle per process, so this runs in a child process."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    mock = os.path.join(root, "tests", "cpp", "_build", "libmock_rccl.so")
+    if not os.path.exists(mock):
+        pytest.skip("tests/cpp/_build/libmock_rccl.so not built (__graft_entry__.build())")
+    code = """
+import importlib, sys
+import numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+srt = importlib.import_module('cuda-spectral-ray-tracer_amd')
+from helpers import assert_planes_equal
+scene = srt.Scene.builtin(srt.SCENE_RANDOM_SPHERES).build_bvh(srt.BVH_SAH, 1984)
+W, H, spp, depth = 150, 90, 12, 16
+cam = scene.default_camera(W, H)
+ref = srt.render_image(scene, cam, W, H, spp, depth)
+for world in (2, 3):
+    comm = srt.Comm.init_all([0] * world)
+    assert comm.world == world and len(comm.renderers) == world
+    for planes in (3, 9):
+        comm.set_gather_planes(planes)
+        comm.upload_scene(scene); comm.set_camera(cam)
+        comm.init_device_params(W, H, spp, depth, 1984)
+        comm.render_frame(W, H); comm.synchronize()
+        root = comm.root
+        assert_planes_equal(root.read_fb(), ref['fb'], 'world %%d planes %%d fb' %% (world, planes))
+        if planes == 9:
+            assert_planes_equal(root.read_fb_aux(2), ref['xyz'], 'world %%d xyz' %% world)
+            assert_planes_equal(root.read_fb_aux(1), ref['lin'], 'world %%d lin' %% world)
+        st = comm.stats()
+        assert st['rays'] == ref['stats']['rays'] and st['paths'] == ref['stats']['paths'], (st, ref['stats'])
+        assert comm.last_gather_ms() > 0.0
+    comm.close()
+print('mock transport ok')
+""" % (root, os.path.join(root, "tests"))
+    env = dict(os.environ, SRT_RCCL_LIB=mock, SRT_COMM_TEST_SAME_DEVICE="1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "mock transport ok" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])
+
+
 def _custom_scene(srt, tris, mats, bg_rgb=(0.5, 0.5, 0.5)):
     """Scene from raw arrays (the boundary's srt_scene_set_* path): tris = [(v0, v1, v2, mat, aa_plane)], mats = [(type, rgb, fuzz, power)]."""
     import ctypes as C
