@@ -896,6 +896,9 @@ __global__ void op_sweep_kernel(int which, const float *a, const float *b, uint3
     // triple (a[k], b[k], a[k ^ 1]): must equal the three compares of is_interior_faster (tri.cu:121-128)
     case 20: { float m = inside_min2(x, y, 0u); asm volatile("" : "+v"(m)); r = inside_min3(m, z, 0u) ? 1.f : 0.f; } break;                      // a1 >= 0 && a2 >= 0 && a3 >= 0
     case 21: { float m = inside_min2(x, y, 0x80000000u); asm volatile("" : "+v"(m)); r = inside_min3(m, z, 0x80000000u) ? 1.f : 0.f; } break;    // a1 <= 0 && a2 <= 0 && a3 <= 0
+    // the product's Sellmeier arithmetic with coefficients B = b[0..2], C = b[3..5] at wavelength a[k]: compared with the reference's
+    // own sellmeier_index compiled from its source (tests/test_ref_tables.py)
+    case 22: r = n >= 6u ? sellmeier_index(b[0], b[1], b[2], b[3], b[4], b[5], x) : 0.f; break;
     default: r = 0.f;
     }
     out[k] = r;

@@ -19,8 +19,11 @@
  *   - Two translation units of the reference hold host data and DO compile unmodified with this image's hipcc (-x hip):
  *     utils/cie_const.cu, utils/color_const.cu (constant tables) -- oracle/Makefile's `ref` target builds them from where they lie into
  *     oracle/_ref/libref_tables.so, and tests/test_ref_tables.py requires the CIE / D65 rows and the XYZ->sRGB matrix of
- *     this oracle AND of the product to equal the reference's arrays bit for bit.  Nothing else of the reference compiles
- *     without stand-ins.
+ *     this oracle AND of the product to equal the reference's arrays bit for bit.  The reference's one curand-free DEVICE function,
+ *     sellmeier_index (refraction/sellmeier.cu), is compiled the same way into oracle/_ref/libref_sellmeier*.so (with a harness kernel
+ *     of ours, oracle/ref_sellmeier_driver.hip) and run on the GPU: orc_sellmeier_index equals it bit for bit when it is built with
+ *     -ffp-contract=off; with the compiler's default contraction 2 % of the operands differ (tests/test_ref_tables.py).  Nothing else
+ *     of the reference compiles without stand-ins.
  *   - What else pins this oracle: the function-level known answers recorded in SURVEY.md 8(c)/Q1/
  *     Q14/Q23 (outputs of the reference's own functions observed in the survey session),
  *     committed as tests/golden/survey_kats.json and checked by tests/test_oracle_kats.py.
