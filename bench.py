@@ -409,7 +409,9 @@ def main():
         # ---- roofline of the dominant kernel (render_kernel) on this rank -------------------------------------------
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import kernel_id
-        my_hash, hash_note = kernel_id.isa_hash()
+        plan = r.launch_plan()
+        variant = "render_kernel<0,%d,%d>" % (int(plan["narrow_refs"]), int(plan["all_cached"]))
+        my_hash, hash_note = kernel_id.isa_hash(int(plan["narrow_refs"]), int(plan["all_cached"]))
         entry, entry_file = None, None
         for f in LANE_OPS_FILES:
             try:
@@ -423,6 +425,7 @@ def main():
                 "peak_arch": ARCH_PEAK_GLANEOPS,
                 "peak_arch_source": "256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz (MI355X_MICROARCH.md: a wave64 VALU instruction issues over 2 cycles; 157.3 TFLOP/s fp32 FMA / 2)"}
         roof["kernel_isa_sha256"] = my_hash
+        roof["kernel"] = variant + ", %d waves per CU, %d of the inner records in LDS" % (plan["waves_per_cu"], plan["n_cached"])
         if entry is not None:
             lane_ops_per_ray = entry["lane_ops_per_ray"]
             pmc_hash = entry.get("kernel_isa_sha256")

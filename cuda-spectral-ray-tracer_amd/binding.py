@@ -85,6 +85,7 @@ PROTOTYPES = {
     "srt_last_error": (C.c_char_p, [_vp]),
     "srt_upload_scene": (_i, [_vp, _vp]),
     "srt_set_camera": (_i, [_vp, C.POINTER(CameraData)]),
+    "srt_launch_plan": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     "srt_init_device_params": (_i, [_vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _u64]),
     "srt_set_partition": (_i, [_vp, _u32, _u32]),
     "srt_render_chunk": (_i, [_vp, _u32, _u32, _u32, _u32, _vp]),

@@ -240,6 +240,17 @@ int srt_set_camera(srt_ctx *c, const srt_camera_data *cam) {
     return SRT_OK;
 }
 
+int srt_launch_plan(const srt_ctx *c, int *waves_per_cu, int *n_cached, int *all_cached, int *narrow_refs) {
+    if (!c || !c->scene_ready) return fail(nullptr, SRT_ERR_INVALID, "srt_launch_plan: no scene uploaded");
+    LaunchPlan plan;
+    render_launch_plan(c->stack_depth, c->n_records, c->n_inner, plan);
+    if (waves_per_cu) *waves_per_cu = plan.waves_per_cu;
+    if (n_cached) *n_cached = plan.n_cached;
+    if (all_cached) *all_cached = plan.all_cached ? 1 : 0;
+    if (narrow_refs) *narrow_refs = c->n_records <= 32767 ? 1 : 0;
+    return SRT_OK;
+}
+
 int srt_init_device_params(srt_ctx *c, uint32_t tx, uint32_t ty, uint32_t bx, uint32_t by, uint32_t chunk_w, uint32_t chunk_h,
                            uint32_t spp, uint32_t bounce_limit, uint64_t seed) {
     if (!c) return fail(c, SRT_ERR_INVALID, "srt_init_device_params: null ctx");

@@ -45,6 +45,12 @@ class Renderer:
     def upload_scene(self, scene):
         self._ck(B.lib().srt_upload_scene(self._h, scene.handle))
 
+    def launch_plan(self):
+        """dict(waves_per_cu, n_cached, all_cached, narrow_refs) of the uploaded scene's render launch"""
+        w, n, a, r = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        self._ck(B.lib().srt_launch_plan(self._h, C.byref(w), C.byref(n), C.byref(a), C.byref(r)))
+        return dict(waves_per_cu=w.value, n_cached=n.value, all_cached=bool(a.value), narrow_refs=bool(r.value))
+
     def set_camera(self, cam):
         self._ck(B.lib().srt_set_camera(self._h, C.byref(cam)))
 

@@ -180,6 +180,10 @@ SRT_API const char *srt_last_error(const srt_ctx *ctx);   /* ctx may be NULL: la
 SRT_API int srt_upload_scene(srt_ctx *ctx, const srt_scene *s);
 /* renderer::assign_cam_data, rendering/rendering.cu:237-242 */
 SRT_API int srt_set_camera(srt_ctx *ctx, const srt_camera_data *cam);
+/* What the render launch of the uploaded scene looks like (diagnostics / measurement bookkeeping): persistent waves per CU, inner
+ * records resident in LDS, whether that is the whole inner tree (kernel variant ALL_CACHED) and whether record references fit 15
+ * bits (variant NARROW).  Any pointer may be NULL. */
+SRT_API int srt_launch_plan(const srt_ctx *ctx, int *waves_per_cu, int *n_cached, int *all_cached, int *narrow_refs);
 /* renderer::init_device_params (rendering/rendering.cu:279-357) + render_manager::init_renderer
  * (render_manager.cu:121-133): threads (tx,ty), grid (bx,by), chunk size, spp, bounce limit, RNG base seed.
  * Allocates the block-linear planar framebuffer and seeds the per-lane RNG states (init_random_states,

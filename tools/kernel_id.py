@@ -14,31 +14,42 @@ ISA = os.path.join(ROOT, "cuda-spectral-ray-tracer_amd", "csrc", "_build", "srt_
 LIB = os.path.join(ROOT, "cuda-spectral-ray-tracer_amd", "libsrt_hip.so")
 
 
-RENDER = re.compile(r"^_ZN3srt13render_kernelILi0E\w+:")      # render_kernel<0, NARROW, ALL_CACHED>: the production builds
+RENDER = re.compile(r"^_ZN3srt13render_kernelILi0ELb([01])ELb([01])E\w*:")      # render_kernel<0, NARROW, ALL_CACHED>: the production builds
 
 
-def isa_hash():
-    """(hash, note) over the bodies of the production render kernels only (label .. s_endpgm of every render_kernel<0,...>): helper
-    kernels of the same translation unit (op sweep, scatter, ...) may change without invalidating a counter pass of the renderer.
-    None when the listing is missing."""
+def isa_hashes():
+    """{(narrow, all_cached): sha256} over the body (label .. s_endpgm) of every production render kernel in the listing: helper
+    kernels of the same translation unit (op sweep, scatter, ...) and the OTHER variants may change without invalidating a counter
+    pass of one variant.  Empty when the listing is missing."""
+    out = {}
     if not os.path.exists(ISA):
-        return None, "no ISA listing (%s)" % os.path.relpath(ISA, ROOT)
-    h = hashlib.sha256()
-    inside, n_kernels = False, 0
+        return out
+    h, key = None, None
     for line in open(ISA, errors="replace"):
-        if not inside and RENDER.match(line):
-            inside, n_kernels = True, n_kernels + 1
-        if not inside:
-            continue
+        if h is None:
+            m = RENDER.match(line)
+            if not m:
+                continue
+            h, key = hashlib.sha256(), (int(m.group(1)), int(m.group(2)))
         body = re.sub(r";.*$", "", line).rstrip()
         if body and not re.match(r"\s*\.(file|ident|loc)\b", body):
             h.update(body.encode() + b"\n")
         if re.match(r"\s*s_endpgm", body):
-            inside = False
-    if n_kernels == 0:
-        return None, "no render_kernel<0,...> in the ISA listing"
-    return h.hexdigest(), "sha256 of the gfx950 ISA of the %d production render kernels (comments and .file/.ident/.loc lines removed)" % n_kernels
+            out[key] = h.hexdigest()
+            h = None
+    return out
+
+
+def isa_hash(narrow=1, all_cached=1):
+    """(hash, note) of one production variant: render_kernel<0, narrow, all_cached> (default: the headline's)."""
+    hs = isa_hashes()
+    if not hs:
+        return None, "no ISA listing (%s)" % os.path.relpath(ISA, ROOT)
+    if (narrow, all_cached) not in hs:
+        return None, "render_kernel<0,%d,%d> not in the ISA listing" % (narrow, all_cached)
+    return hs[(narrow, all_cached)], "sha256 of the gfx950 ISA of render_kernel<0,%d,%d> (comments and .file/.ident/.loc lines removed)" % (narrow, all_cached)
 
 
 if __name__ == "__main__":
-    print(isa_hash()[0])
+    for k, v in sorted(isa_hashes().items()):
+        print("render_kernel<0,%d,%d> %s" % (k[0], k[1], v))
