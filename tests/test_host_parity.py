@@ -210,3 +210,49 @@ def test_reference_quirks_switch(srt, orc):
         assert np.allclose(sd_off, 0.73, atol=1e-6)
     finally:
         assert L.srt_set_reference_quirks(1) == 0
+
+
+def _unique_vertices(tris, tol=1e-3):
+    pts = []
+    for t in tris:
+        for v in (t.v0, t.v1, t.v2):
+            p = np.array(list(v), np.float64)
+            if not any(np.linalg.norm(p - q) < tol for q in pts):
+                pts.append(p)
+    return np.array(pts)
+
+
+def test_cornell_geometry_is_a_rigid_arrangement_of_the_reference_numbers(srt):
+    """SURVEY f1 (scene construction beyond PRISM: tri_box / pyramid / transform restated from primitives/tri_box.cu:4-34,
+    pyramid.cu:3-35, transform.cu:4-34; scene/scene.cu:74-130) has no fixture upstream and stays 'parity unpinned'.  What CAN be
+    checked without the reference's output: the objects are rigid bodies built from the numbers in scene.cu -- boxes of 165 x 330 x
+    165 and 165^3 with right angles, closed (12 triangles on 8 vertices), standing on the floor, turned about the vertical axis by
+    25 and 18 degrees and shifted by the reference's translations; a pyramid over a 165-square at height 166 with its apex 165
+    above the square's centre.  A wrong rotation matrix, a non-orthogonal transform or a mis-placed pivot fails this."""
+    scene = srt.Scene.builtin(srt.SCENE_CORNELL, 0)
+    tris = scene.triangles()
+    assert len(tris) == 42                                   # 5 walls + light (12), two boxes (24), pyramid (6): scene.cu:83-128
+    for first, dims, angle, shift in ((12, (165.0, 330.0, 165.0), 25.0, (265.0, 295.0)), (24, (165.0, 165.0, 165.0), 18.0, (130.0, 65.0))):
+        v = _unique_vertices(tris[first:first + 12])
+        assert v.shape[0] == 8
+        d = np.sort(np.linalg.norm(v[:, None, :] - v[None, :, :], axis=2), axis=1)[:, 1:]      # distances to the 7 other corners
+        a, b, c = sorted(dims)
+        want = sorted([a, b, c, np.hypot(a, b), np.hypot(a, c), np.hypot(b, c), np.sqrt(a * a + b * b + c * c)])
+        assert np.allclose(d, np.array(want)[None, :], atol=2e-3)                               # every corner of a right-angled box
+        ys = np.sort(np.unique(np.round(v[:, 1], 3)))
+        assert np.allclose(ys, [0.0, dims[1]], atol=1e-3)                                       # stands on the floor, upright
+        base = v[np.abs(v[:, 1]) < 1e-3][:, [0, 2]]
+        centre = base.mean(axis=0)
+        assert np.allclose(centre, (shift[0] + dims[0] / 2, shift[1] + dims[2] / 2), atol=1e-3)  # rotated about its own centre, then translated
+        e = base - centre
+        ang = np.degrees(np.arctan2(e[:, 1], e[:, 0])) % 90.0                                   # corner directions: 45 deg +- the rotation
+        assert np.allclose(np.minimum(np.abs(ang - (45.0 + angle) % 90.0), np.abs(ang - (45.0 - angle) % 90.0)), 0.0, atol=1e-3)
+    v = _unique_vertices(tris[36:42])
+    assert v.shape[0] == 5
+    apex = v[np.argmax(v[:, 1])]
+    base = v[np.abs(v[:, 1] - 166.0) < 1e-3]
+    assert base.shape[0] == 4 and abs(apex[1] - 331.0) < 1e-3
+    assert np.allclose(base[:, [0, 2]].mean(axis=0), apex[[0, 2]], atol=1e-3)                   # apex over the centre of the base
+    side = np.sort(np.linalg.norm(base[:, None, :] - base[None, :, :], axis=2), axis=1)
+    assert np.allclose(side[:, 1:], [[165.0, 165.0, 165.0 * np.sqrt(2.0)]] * 4, atol=2e-3)      # a 165-square
+    assert np.allclose(base[:, [0, 2]].mean(axis=0), (130.0 + 82.5, 65.0 + 82.5), atol=1e-3)    # same pivot and shift as the small box
