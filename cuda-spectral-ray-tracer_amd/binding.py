@@ -75,6 +75,7 @@ PROTOTYPES = {
     "srt_fit_sigmoid_coeffs": (_i, [_fp, _fp]),
     "srt_color_tables": (_i, [_fp, _fp]),
     "srt_background_spectrum": (_i, [_fp, _fp]),
+    "srt_rotation_matrix": (_i, [_f, _i, _fp]),
     "srt_scene_build_bvh": (_i, [_vp, _i, _u64]),
     "srt_scene_order_children": (_i, [_vp, _fp]),
     "srt_scene_node_count": (_sz, [_vp]),
@@ -86,6 +87,7 @@ PROTOTYPES = {
     "srt_upload_scene": (_i, [_vp, _vp]),
     "srt_set_camera": (_i, [_vp, C.POINTER(CameraData)]),
     "srt_launch_plan": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
+    "srt_launch_lds_bytes": (_i, [_vp, C.POINTER(_sz)]),
     "srt_init_device_params": (_i, [_vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _u64]),
     "srt_set_partition": (_i, [_vp, _u32, _u32]),
     "srt_render_chunk": (_i, [_vp, _u32, _u32, _u32, _u32, _vp]),

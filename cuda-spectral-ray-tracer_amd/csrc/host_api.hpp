@@ -190,6 +190,8 @@ public:
     const float *getDevFBb() const { return plane(2); }
     srt_ctx *getContext() const { return ctx; }
     bool isDeviceInited() const { return device_inited; }
+    // dynamic LDS bytes of one workgroup of the render launch: this build's counterpart of shared_mem_size (rendering.cu:290-301)
+    size_t getSharedMemSize() const { size_t b = 0; if (ctx) (void)srt_launch_lds_bytes(ctx, &b); return b; }
     // first failing status of any call made through this object (0 = none): the reference exits the process from
     // checkCudaErrors (utils/cuda_utility.cu:8-18); here the caller decides
     int getError() const { return first_error.load(); }
@@ -335,6 +337,7 @@ public:
     }
     bool isDone() const { return done.load(); }
     int getError() const { return first_error.load() ? first_error.load() : r.getError(); }   // 0 = every chunk rendered
+    size_t getLdsBytes() const { return r.getSharedMemSize(); }
     uint64_t getTotalRays() const { return total_rays; }   // closest-hit queries of all chunks rendered so far
     uint getImWidth() const { return image_width; }
     uint getImHeight() const { return image_height; }

@@ -251,6 +251,14 @@ int srt_launch_plan(const srt_ctx *c, int *waves_per_cu, int *n_cached, int *all
     return SRT_OK;
 }
 
+int srt_launch_lds_bytes(const srt_ctx *c, size_t *bytes) {
+    if (!c || !c->scene_ready || !bytes) return fail(nullptr, SRT_ERR_INVALID, "srt_launch_lds_bytes: no scene uploaded / null argument");
+    LaunchPlan plan;
+    render_launch_plan(c->stack_depth, c->n_records, c->n_inner, plan);
+    *bytes = render_lds_bytes(c->stack_depth, plan.waves_per_block, plan.n_cached, c->n_records);
+    return SRT_OK;
+}
+
 int srt_init_device_params(srt_ctx *c, uint32_t tx, uint32_t ty, uint32_t bx, uint32_t by, uint32_t chunk_w, uint32_t chunk_h,
                            uint32_t spp, uint32_t bounce_limit, uint64_t seed) {
     if (!c) return fail(c, SRT_ERR_INVALID, "srt_init_device_params: null ctx");

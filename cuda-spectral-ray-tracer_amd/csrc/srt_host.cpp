@@ -321,7 +321,7 @@ int build_bvh_sah(srt_scene &s) {
             auto dist2 = [&](const Box &bx) {
                 double d2 = 0;
                 for (int ax = 0; ax < 3; ax++) {
-                    const double p = s.cam.lookfrom[ax];
+                    const double p = s.has_order_eye ? s.order_eye[ax] : s.cam.lookfrom[ax];
                     const double d = p < bx.lo[ax] ? bx.lo[ax] - p : (p > bx.hi[ax] ? p - bx.hi[ax] : 0.0);
                     d2 += d * d;
                 }
@@ -557,6 +557,20 @@ static bool grey_coeffs(const float rgb[3], float c[3]) {   // :118-120
 // A "shape" is a list of indices into the scene's triangle list; every triangle carries its sticky
 // aa_plane state exactly as tri::init leaves it.
 // ------------------------------------------------------------------------------------------------------
+// transform::assign_rot_matrix (primitives/transform.cu:4-34; axis = transform::AXIS: 1 X, 2 Y, 3 Z).  Exported as
+// srt_rotation_matrix and held bit for bit against the reference's own function (tests/test_ref_host.py).
+// `cos(theta)` with a float argument: the reference's translation unit, compiled here from its source, binds the call to the
+// double function and narrows the result (cvtss2sd / call cos / cvtsd2ss in its host object), which differs from cosf by an ulp for
+// about one angle in a hundred -- none of the three angles the scenes use (+25, -18, +10 degrees give the same bits either way).
+// The double form is what the compiled reference computes, so it is what this build computes; what nvcc's device overload
+// resolution makes of the same line is unknowable here.
+static void assign_rot_matrix(float theta, int axis, float m[9]) {
+    const float c = (float)cos((double)theta), sn = (float)sin((double)theta);
+    if (axis == 1) { m[4] = c; m[5] = -sn; m[7] = sn; m[8] = c; }
+    else if (axis == 2) { m[0] = c; m[2] = sn; m[6] = -sn; m[8] = c; }
+    else if (axis == 3) { m[0] = c; m[1] = -sn; m[3] = sn; m[4] = c; }
+}
+
 struct Builder {
     srt_scene &s;
     explicit Builder(srt_scene &sc) : s(sc) {}
@@ -619,10 +633,7 @@ struct Builder {
     // tri::rotate(theta, ax, false, false) (tri.cu:96-118) with transform::assign_rot_matrix (transform.cu:4-34)
     void rotate_about_origin(const std::vector<int> &tris, float theta, int axis /*1=X 2=Y 3=Z*/) {
         float m[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f};
-        const float c = cosf(theta), sn = sinf(theta);
-        if (axis == 1) { m[4] = c; m[5] = -sn; m[7] = sn; m[8] = c; }
-        else if (axis == 2) { m[0] = c; m[2] = sn; m[6] = -sn; m[8] = c; }
-        else if (axis == 3) { m[0] = c; m[1] = -sn; m[3] = sn; m[4] = c; }
+        assign_rot_matrix(theta, axis, m);
         for (int k : tris)
             for (int cidx = 0; cidx < 3; cidx++) {
                 F3 v = V(k, cidx);   // vec3::matrix_mul, vec3.cuh:80-91
@@ -1191,7 +1202,13 @@ int srt_scene_order_children(srt_scene *s, const float eye[3]) {
     };
     for (BvhNode &nd : s->nodes)
         if (nd.left >= 0 && nd.right >= 0 && dist2(s->nodes[nd.right].box) < dist2(s->nodes[nd.left].box)) std::swap(nd.left, nd.right);
-    s->cam.lookfrom[0] = eye[0]; s->cam.lookfrom[1] = eye[1]; s->cam.lookfrom[2] = eye[2];
+    // a later SAH rebuild orders for the same viewpoint; the scene's default camera is NOT touched (srt_scene_default_camera)
+    s->order_eye[0] = eye[0]; s->order_eye[1] = eye[1]; s->order_eye[2] = eye[2]; s->has_order_eye = true;
+    return SRT_OK;
+}
+int srt_rotation_matrix(float theta, int axis, float m[9]) {
+    if (!m) { set_global_error("srt_rotation_matrix: null matrix"); return SRT_ERR_INVALID; }
+    assign_rot_matrix(theta, axis, m);
     return SRT_OK;
 }
 size_t srt_scene_node_count(const srt_scene *s) { return (s && s->bvh_valid) ? s->nodes.size() : 0; }

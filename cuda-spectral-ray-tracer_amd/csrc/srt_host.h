@@ -54,7 +54,10 @@ struct srt_scene {
     int32_t root = -1;
     int depth = 0;            // max number of internal nodes on a root-to-leaf path
     bool bvh_valid = false;
-    srt::CameraSetup cam;
+    srt::CameraSetup cam;     // the scene's DEFAULT camera (srt_scene_default_camera); never modified after construction
+    // viewpoint the SAH builder / srt_scene_order_children put the nearer child on the left for; unset = the default camera's
+    float order_eye[3] = {0.f, 0.f, 0.f};
+    bool has_order_eye = false;
     int scene_id = -1;
     std::string name;
 };

@@ -20,130 +20,27 @@
 #include <vector>
 
 #include "host_api.hpp"
+#include "srt_cli.hpp"
 
 namespace fs = std::filesystem;
 using namespace srt_host;
 
-namespace {
-
-const char *kSceneNames[] = {"Cornell Box", "Prism World", "Different Materials"};   // io/params.h:19
-
-struct parameters {   // io/params.h:21-223
-    std::string image_title, log_subdir;
-    uint scene = 0, xres = 600, yres = 600;
-    float ar = 1.0f;
-    uint xcsize = 0, ycsize = 0, n_samples = 500, bounce_limit = 10;
-    bool do_log = false, show_render = true, do_save = false;
-    int gpu = 0;
-    int gpus = 1;      // --gpus N: devices 0 .. N-1 of this node render interleaved tiles of every chunk (one RCCL gather per chunk)
-    bool sah = false;
-
-    void resetYres() { yres = static_cast<uint>(xres / ar); yres = (yres < 1) ? 1 : yres; }   // params.h:176-180
-    uint getXcsize() const { uint r = xcsize == 0 ? ycsize : xcsize; return r == 0 ? xres : r; }   // :53-57
-    uint getYcsize() const { uint r = ycsize == 0 ? xcsize : ycsize; return r == 0 ? yres : r; }   // :59-63
-    std::string getImgTitle() const {
-        if (!image_title.empty()) return image_title;
-        return scene < 3 ? std::string(kSceneNames[scene]) : ("Scene " + std::to_string(scene));
-    }
-};
-
-float parseAR(const std::string &s) {   // params.h:182-195
-    std::stringstream ss(s);
-    std::string num;
-    std::getline(ss, num, '/');
-    float ar = std::stof(num);
-    if (std::getline(ss, num, '/')) ar /= std::stof(num);
-    return ar;
-}
-
-bool parseArgs(int argc, char **argv, parameters &p) {   // params.h:236-304
-    for (int i = 1; i < argc; i++) {
-        const std::string arg(argv[i]);
-        const bool is_last = i + 1 == argc;
-        try {
-            if (!is_last && (arg == "-t" || arg == "--title")) p.image_title = argv[++i];
-            else if (!is_last && (arg == "-lsub" || arg == "--log-subdir")) p.log_subdir = argv[++i];
-            else if (!is_last && (arg == "-s" || arg == "--scene")) p.scene = (uint)std::stoul(argv[++i]);
-            else if (!is_last && (arg == "-xr" || arg == "--xres")) { p.xres = (uint)std::stoul(argv[++i]); p.resetYres(); }
-            else if (!is_last && (arg == "-ar" || arg == "--aspect-ratio")) { p.ar = parseAR(argv[++i]); p.resetYres(); }
-            else if (!is_last && (arg == "-xc" || arg == "--xcsize")) p.xcsize = (uint)std::stoul(argv[++i]);
-            else if (!is_last && (arg == "-yc" || arg == "--ycsize")) p.ycsize = (uint)std::stoul(argv[++i]);
-            else if (!is_last && (arg == "-ns" || arg == "--nsamples")) p.n_samples = (uint)std::stoul(argv[++i]);
-            else if (!is_last && (arg == "-bl" || arg == "--bounce-limit")) p.bounce_limit = (uint)std::stoul(argv[++i]);
-            else if (!is_last && arg == "--gpu") p.gpu = std::stoi(argv[++i]);
-            else if (!is_last && arg == "--gpus") p.gpus = std::max(1, std::stoi(argv[++i]));
-            else if (arg == "--sah") p.sah = true;
-            else if (arg == "--physically-correct") srt_set_reference_quirks(0);      // Q1 / Q2 off (not parity-checked)
-            else if (arg == "--reference-quirks") srt_set_reference_quirks(1);        // the default
-            else if (arg == "--do-log") p.do_log = true;
-            else if (arg == "--no-show") p.show_render = false;
-            else if (arg == "--save") p.do_save = true;
-            else std::cout << "Unkown argument name: " << arg << std::endl;
-        } catch (...) {
-            std::cerr << "Error while parsing " << arg << " arg value, keeping previous (default most likely) value" << std::endl;
-        }
-    }
-    return true;
-}
-
-void string_to_filename(std::string &str) {   // utils/utility.h:32-41
-    for (char &c : str) c = (c == ' ') ? '_' : (char)std::tolower(static_cast<unsigned char>(c));
-}
-
-// _log_/log_context.{h,cpp}: ordered key: value lines -> logs/[subdir/]<epoch_ms>_<title>_log.txt
-struct log_context {
-    std::vector<std::string> order;
-    std::map<std::string, std::string> data;
-    std::string title, subdir;
-    void add_entry(const std::string &name, const std::string &value) { order.push_back(name); data[name] = value; }
-    template <typename T> void add_entry(const std::string &name, T value) {
-        std::ostringstream oss;
-        if constexpr (std::is_floating_point<T>::value) oss << std::setprecision(std::numeric_limits<T>::digits10 + 1);
-        oss << value;
-        add_entry(name, oss.str());
-    }
-    void to_file() const {
-        fs::path dir = fs::path("logs") / subdir;
-        fs::create_directories(dir);
-        const auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::system_clock::now().time_since_epoch()).count();
-        std::string name = std::to_string(ms) + "_" + title + "_log.txt";
-        string_to_filename(name);
-        const fs::path file = dir / name;
-        std::ofstream out(file);
-        if (!out.is_open()) { std::cerr << "Failed to save log file at: " << file.string() << std::endl; return; }
-        for (const auto &k : order) out << k << ": " << data.at(k) << "\n";
-        std::clog << "Log file saved successfully at: " << file.string() << std::endl;
-    }
-};
-
-// io/save_image.cpp:8-20 (renders/<file>), image/image.cpp:3-18: 24-bit BMP, bottom-up rows, BGR
-bool save_img(const image_channels &ch, uint width, uint height, const std::string &filename) {
-    const fs::path p = fs::path("renders") / filename;
-    fs::create_directories(p.parent_path());
-    const uint32_t row = (width * 3 + 3) & ~3u, size = 54 + row * height;
-    std::vector<unsigned char> buf(size, 0);
-    auto put32 = [&](size_t off, uint32_t v) { buf[off] = v & 255; buf[off + 1] = (v >> 8) & 255; buf[off + 2] = (v >> 16) & 255; buf[off + 3] = (v >> 24) & 255; };
-    buf[0] = 'B'; buf[1] = 'M';
-    put32(2, size); put32(10, 54); put32(14, 40); put32(18, width); put32(22, height);
-    buf[26] = 1; buf[28] = 24; put32(34, row * height);
-    for (uint y = 0; y < height; y++)
-        for (uint x = 0; x < width; x++) {
-            unsigned char *px = &buf[54 + (size_t)(height - 1 - y) * row + 3 * (size_t)x];
-            const size_t k = (size_t)y * width + x;
-            px[0] = ch.b[k]; px[1] = ch.g[k]; px[2] = ch.r[k];
-        }
-    std::ofstream out(p, std::ios::binary);
-    if (!out.is_open()) return false;
-    out.write(reinterpret_cast<const char *>(buf.data()), (std::streamsize)buf.size());
-    std::clog << "Image saved as: " << p.filename() << std::endl;
-    return true;
-}
-
-}  // namespace
+using namespace srt_cli;
 
 int main(int argc, char **argv) {
     parameters pm;
     parseArgs(argc, argv, pm);
+    if (pm.quirks >= 0) srt_set_reference_quirks(pm.quirks);
+    for (int i = 1; i < argc; i++)
+        if (std::string(argv[i]) == "--dump-params") {
+            // what the flags were understood as, one `key=value` line each, then exit: no scene, no GPU (tests/test_ref_host.py holds
+            // these against param_manager::parseArgs of the reference's own io/params.h)
+            std::cout << "title=" << pm.getImgTitle() << "\nlog_subdir=" << pm.log_subdir << "\nscene=" << pm.scene << "\nxres=" << pm.xres
+                      << "\nyres=" << pm.yres << "\nar=" << std::setprecision(9) << pm.ar << "\nxcsize=" << pm.getXcsize() << "\nycsize=" << pm.getYcsize()
+                      << "\nn_samples=" << pm.n_samples << "\nbounce_limit=" << pm.bounce_limit << "\ndo_log=" << pm.do_log
+                      << "\nshow_render=" << pm.show_render << "\ndo_save=" << pm.do_save << std::endl;
+            return 0;
+        }
     std::cout << "Image Title: " << pm.getImgTitle() << std::endl;
     if (!pm.log_subdir.empty()) std::cout << "Log Subdir: " << pm.log_subdir << std::endl;
     std::cout << "Scene: " << (pm.scene < 3 ? kSceneNames[pm.scene] : "synthetic") << " (ID: " << pm.scene << ")" << std::endl;
@@ -181,6 +78,10 @@ int main(int argc, char **argv) {
     rm.init_device_params(pm.getXcsize(), pm.getYcsize());
     lc.add_entry("chunk width", pm.getXcsize());                            // rendering.cu:337-349
     lc.add_entry("chunk height", pm.getYcsize());
+    lc.add_entry("chunk total byte size", (size_t)(pm.getXcsize() * pm.getYcsize()) * 12u);          // max_num_pixels * sizeof(vec3), rendering.cu:341
+    // the reference logs its dynamic shared memory (95*4 + 128*56 + 448*36 + 32*428 = 37 372 B, rendering.cu:290-301,342); this
+    // build's launch uses its own LDS plan (inner tree + stacks): the key is kept, the value is this build's
+    lc.add_entry("shared memory byte size", rm.getLdsBytes());
     lc.add_entry("threads x", 28u); lc.add_entry("threads y", 16u); lc.add_entry("threads z", 1u);
     lc.add_entry("blocks x", pm.getXcsize() / 28 + 1); lc.add_entry("blocks y", pm.getYcsize() / 16 + 1); lc.add_entry("blocks z", 1u);
     if (!rm.isReadyToRender()) { std::cerr << "Device parameters not yet initialized" << std::endl; return 1; }
@@ -205,7 +106,7 @@ int main(int argc, char **argv) {
     if (pm.do_log) lc.to_file();
     std::string image_filename = pm.getImgTitle() + ".bmp";
     string_to_filename(image_filename);
-    if (pm.do_save) save_img(ch, pm.xres, pm.yres, image_filename);
+    if (pm.do_save) save_img(ch.r, ch.g, ch.b, pm.xres, pm.yres, image_filename);
     if (rm.getError() != SRT_OK) { std::cerr << "render failed with status " << rm.getError() << " (the image is incomplete)" << std::endl; return 3; }
     return 0;
 }

@@ -152,6 +152,13 @@ SRT_API int srt_fit_sigmoid_coeffs(const float rgb[3], float coeffs[3]);
 SRT_API int srt_color_tables(float cmf[SRT_N_CIE_SAMPLES * 4], float xyz_to_srgb[9]);
 SRT_API int srt_background_spectrum(const float rgb[3], float out[SRT_N_CIE_SAMPLES]);
 
+/* transform::assign_rot_matrix (primitives/transform.cu:4-34): writes the rotation entries of a row-major 3x3 matrix for `axis`
+ * 1 = X, 2 = Y, 3 = Z (transform::AXIS, transform.cuh:5-10) into m, which the caller initialised (the reference starts from the
+ * identity, tri.cu:97-99); other axis values leave m untouched.  Points are rotated as vec3::matrix_mul does (math/vec3.cuh:80-91):
+ * out[i] = m[3i] x + m[3i+1] y + m[3i+2] z.  The matrix the built-in scenes' boxes / pyramid / prism are turned with
+ * (scene/scene.cu:115-128,166); tests/test_ref_host.py holds it against the reference's own function compiled from its source. */
+SRT_API int srt_rotation_matrix(float theta, int axis, float m[9]);
+
 /* BVH: `mode` SRT_BVH_REFERENCE reproduces create_bvh_kernel (fresh XORWOW(seed), bvh/bvh.cu:206-346);
  * SRT_BVH_SAH is this build's builder.  Either way the node semantics are the reference's: binary tree,
  * one triangle per leaf, leaf box = padded triangle box, internal box = union of children (Q22). */
@@ -184,6 +191,9 @@ SRT_API int srt_set_camera(srt_ctx *ctx, const srt_camera_data *cam);
  * records resident in LDS, whether that is the whole inner tree (kernel variant ALL_CACHED) and whether record references fit 15
  * bits (variant NARROW).  Any pointer may be NULL. */
 SRT_API int srt_launch_plan(const srt_ctx *ctx, int *waves_per_cu, int *n_cached, int *all_cached, int *narrow_refs);
+/* Dynamic LDS bytes of one workgroup of that launch (tables + inner-record cache + traversal stacks): the counterpart of the
+ * reference's shared_mem_size (rendering/rendering.cu:290-301), which its run log reports as "shared memory byte size" (:342). */
+SRT_API int srt_launch_lds_bytes(const srt_ctx *ctx, size_t *bytes);
 /* renderer::init_device_params (rendering/rendering.cu:279-357) + render_manager::init_renderer
  * (render_manager.cu:121-133): threads (tx,ty), grid (bx,by), chunk size, spp, bounce limit, RNG base seed.
  * Allocates the block-linear planar framebuffer and seeds the per-lane RNG states (init_random_states,

@@ -153,6 +153,23 @@ def test_sigmoid_fit_round_trip(srt, orc):
     assert red[60] > 5 * red[20] and blue[20] > 3 * blue[70] and green[38] > 3 * green[80]
 
 
+def test_order_children_leaves_the_default_camera_alone(srt):
+    """srt_scene_order_children used to overwrite the scene's default lookfrom with `eye`, so a later
+    srt_scene_default_camera rendered from there with the old lookat / focus distance.  The default camera is a property of the
+    scene (scene/scene.cu:259-320) and must be bit-identical before and after; a SAH rebuild afterwards keeps ordering for `eye`."""
+    import ctypes as C
+    for sid, mode in ((srt.SCENE_RANDOM_SPHERES, srt.BVH_SAH), (srt.SCENE_CORNELL, srt.BVH_REFERENCE)):
+        scene = srt.Scene.builtin(sid, 0).build_bvh(mode)
+        before = bytes(scene.default_camera(320, 200))
+        scene.order_children((-7.0, 3.5, 11.0))
+        assert bytes(scene.default_camera(320, 200)) == before
+        l1 = scene.bvh()[0].copy()
+        if mode == srt.BVH_SAH:
+            scene.build_bvh(mode)                      # rebuilt for the same viewpoint: same child order as the re-ordered tree
+            assert bytes(scene.default_camera(320, 200)) == before
+            assert np.array_equal(scene.bvh()[0], l1)
+
+
 def test_order_children_for_a_viewpoint(srt, orc):
     """srt_scene_order_children: same topology / boxes / depth, every internal node's nearer child (to the eye) on the left; the
     tree stays a valid input for the oracle (which imports it) -- GPU/oracle parity on a re-ordered tree is covered by the GPU suite."""
@@ -232,7 +249,7 @@ def test_cornell_geometry_is_a_rigid_arrangement_of_the_reference_numbers(srt):
     scene = srt.Scene.builtin(srt.SCENE_CORNELL, 0)
     tris = scene.triangles()
     assert len(tris) == 42                                   # 5 walls + light (12), two boxes (24), pyramid (6): scene.cu:83-128
-    for first, dims, angle, shift in ((12, (165.0, 330.0, 165.0), 25.0, (265.0, 295.0)), (24, (165.0, 165.0, 165.0), 18.0, (130.0, 65.0))):
+    for first, dims, angle, shift in ((12, (165.0, 330.0, 165.0), 25.0, (265.0, 295.0)), (24, (165.0, 165.0, 165.0), -18.0, (130.0, 65.0))):
         v = _unique_vertices(tris[first:first + 12])
         assert v.shape[0] == 8
         d = np.sort(np.linalg.norm(v[:, None, :] - v[None, :, :], axis=2), axis=1)[:, 1:]      # distances to the 7 other corners
@@ -244,9 +261,11 @@ def test_cornell_geometry_is_a_rigid_arrangement_of_the_reference_numbers(srt):
         base = v[np.abs(v[:, 1]) < 1e-3][:, [0, 2]]
         centre = base.mean(axis=0)
         assert np.allclose(centre, (shift[0] + dims[0] / 2, shift[1] + dims[2] / 2), atol=1e-3)  # rotated about its own centre, then translated
+        # SIGNED turning angle: the reference's Y matrix (transform.cu:18-23, pinned against its compiled function in
+        # tests/test_ref_host.py) maps (x, z) to (c x + s z, -s x + c z), i.e. a corner direction phi goes to phi - angle
         e = base - centre
-        ang = np.degrees(np.arctan2(e[:, 1], e[:, 0])) % 90.0                                   # corner directions: 45 deg +- the rotation
-        assert np.allclose(np.minimum(np.abs(ang - (45.0 + angle) % 90.0), np.abs(ang - (45.0 - angle) % 90.0)), 0.0, atol=1e-3)
+        ang = np.degrees(np.arctan2(e[:, 1], e[:, 0])) % 90.0
+        assert np.allclose(ang, (45.0 - angle) % 90.0, atol=1e-3), (ang, angle)
     v = _unique_vertices(tris[36:42])
     assert v.shape[0] == 5
     apex = v[np.argmax(v[:, 1])]

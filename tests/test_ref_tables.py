@@ -2,8 +2,9 @@
 with this image's hipcc (-x hip; recipe: oracle/Makefile, target `ref`, output oracle/_ref/libref_tables.so, git-ignored, built
 by __graft_entry__.build() where /root/reference is mounted).  The CIE 1931 colour matching functions, the normalised D65
 illuminant and the XYZ -> sRGB matrix that the product (srt_color_tables) and the oracle compute with must equal the reference's
-arrays bit for bit.  Nothing else of the reference compiles here without stand-ins for CUDA headers, so this is the whole extent
-of "the reference compiled here" (DESIGN.md section 2)."""
+arrays bit for bit.  The other pieces of the reference that compile here without stand-ins for CUDA headers: sellmeier_index (below),
+and the host files transform.cu / params.cpp / log_context.cpp / image.cpp / save_image.cpp (tests/test_ref_host.py); everything on
+the render path proper needs curand_kernel.h and cannot be built."""
 import ctypes as C
 import os
 import subprocess
@@ -77,7 +78,7 @@ def test_reference_sellmeier_device_function(srt, orc, gpu):
     sets = [(flint_b, flint_b), (flint_b, flint_c), (bk7_b, bk7_b), (bk7_b, bk7_c)] + \
            [(tuple(rng.uniform(0.1, 2.0, 3)), tuple(rng.uniform(0.001, 120.0, 3))) for _ in range(4)]
     n = 1 << 14
-    n_nan, n_total, n_contract_differs, ulps = 0, 0, 0, []
+    n_nan, n_total, n_contract_differs, ulps, n_nan_flips = 0, 0, 0, [], 0
     for b3, c3 in sets:
         b = np.array(b3, np.float32); c = np.array(c3, np.float32)
         lam = rng.uniform(300.0, 900.0, n).astype(np.float32)
@@ -98,8 +99,9 @@ def test_reference_sellmeier_device_function(srt, orc, gpu):
         fin = np.isfinite(ref) & np.isfinite(ref_c)
         d = np.abs(ref.view(np.int32).astype(np.int64) - ref_c.view(np.int32).astype(np.int64))[fin]
         n_contract_differs += int(np.sum(d != 0)); ulps.append(d)
-        assert np.all(np.isnan(ref) == np.isnan(ref_c)) or True      # (NaN sets may differ next to a pole; counted below)
+        n_nan_flips += int(np.sum(np.isnan(ref) != np.isnan(ref_c)))  # next to a pole the contracted build may land on the other side of it
     assert n_nan > 0                                   # quirk Q1 really produces NaN indices somewhere in the sweep
+    assert n_nan_flips <= n_total // 1000              # ... and contraction moves an operand across NaN / finite only at a pole: a counted handful
     ulps = np.concatenate(ulps)
     frac = n_contract_differs / n_total
     print("contraction build differs from the IEEE reading in %.2f %% of the operands; median / 99th percentile / max ulp distance of those: %d / %d / %d"
