@@ -8,11 +8,19 @@ srt_render_frame_multi) brings the compact tile buffers to rank 0, which scatter
 block-linear planar framebuffer in HBM.  Scene, camera and RNG states are resident in HBM before the timed
 region.  The image is fixed, so N GPUs split the same work: scaling is "strong".
 
-  python bench.py --gpus 1 --steps K --warmup W
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-         bench.py --gpus N --steps K --warmup W
+Three ways to start it (config.launch_mode says which one ran):
 
-Rank 0 prints ONE JSON line.
+  python bench.py --gpus 1 --steps K --warmup W                      one GPU
+  python bench.py --gpus N --steps K --warmup W                      ONE process drives N GPUs: srt_comm_init_all (ncclCommInitAll,
+                                                                     one HIP stream per device) -- SURVEY 8(e)'s shape
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W                      one process per GPU: srt_comm_init_rank; torch.distributed carries
+                                                                     the 128-byte communicator id, the barriers and the statistics
+
+Rank 0 prints ONE JSON line.  Besides the headline it carries
+  cfg5            one frame of BASELINE cfg 5 as specified (100k-triangle mesh, 3840x2160, 4096 spp) on the same N GPUs,
+  other_configs   (N = 1) cfg 2, cfg 4 and cfg 5's scene at 512 spp, each with V, T, kernel time and its own roofline entry,
+  roofline        the render kernel against what binds it (see below), cpu_baseline (N = 1) the CPU oracle on this box's host cores.
 
 `roofline` prices the render kernel against what actually binds it.  The scene is LDS / L2 resident, so HBM is
 not the roof (the SURVEY 8(d) HBM figure is kept under roofline.hbm, against the copy bandwidth measured in this
@@ -42,10 +50,12 @@ sys.path.insert(0, ROOT)
 
 HBM_SPEC_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); the copy rate is measured below
 NODE_BYTES, TRI_BYTES, MAT_BYTES = 64, 48, 56
-LANE_OPS_FILES = [os.path.join(ROOT, "profiles", r, "lane_ops_per_ray.json") for r in ("r03", "r02")]      # newest first
+LANE_OPS_FILES = [os.path.join(ROOT, "profiles", r, "lane_ops_per_ray.json") for r in ("r04", "r03", "r02")]      # newest first
 ARCH_PEAK_GLANEOPS = 256 * 4 * 32 * 2.4      # G lane-op/s: 256 CU x 4 SIMD x 32 lanes per clock x 2.4 GHz (157.3 TFLOP/s fp32 FMA / 2)
 SCENE_NAMES = {0: "reference CORNELL scene", 1: "reference PRISM scene", 2: "reference TRIS scene", 100: "random-spheres tri scene",
                101: "100k-triangle mesh in the Cornell shell"}
+BVH_NAMES = {1: "SAH (exact sweep below 8192 triangles, 256 bins above), one triangle per leaf, children ordered by distance to the scene's default camera",
+             0: "reference builder (bvh/bvh.cu:206-346)"}
 
 
 def log(msg):
@@ -168,6 +178,478 @@ def measure_hbm_copy_gbs(torch):
     return 2 * n * 4 / (ms * 1e-3) / 1e9
 
 
+def checksum_of(renderer):
+    fb = renderer.read_fb()
+    return int(sum(int(p.astype("int64").sum()) for p in fb))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# The ranks of the job as THIS process sees them.  Three shapes behind one interface:
+#   upload(scene, cam) / init_params(W, H, spp, depth) / set_count(on) / frame(W, H) -- one complete frame incl. the exchange,
+#   returns when it is done -- / barrier() / local (the renderers this process drives) / root (rank 0's renderer or None)
+# ----------------------------------------------------------------------------------------------------------------------
+class OneGpu:
+    launch_mode = "one process, one GPU"
+
+    def __init__(self, srt, torch, device):
+        self.torch, self.world, self.rank = torch, 1, 0
+        self.r = srt.Renderer(device)
+        self.local, self.root = [self.r], self.r
+        self.stream = torch.cuda.current_stream().cuda_stream
+        self.gather_via, self.gather_check = "none (1 GPU)", None
+
+    def upload(self, scene, cam):
+        self.r.upload_scene(scene); self.r.set_camera(cam); self.r.set_partition(0, 1)
+
+    def init_params(self, W, H, spp, depth):
+        self.r.init_device_params(W, H, spp, depth, 1984)
+
+    def set_count(self, on):
+        self.r.set_count_traversal(on)
+
+    def frame(self, W, H):
+        self.r.render_chunk(W, H, 0, 0, self.stream)
+        self.r.scatter_tiles(None, self.stream)
+        self.torch.cuda.synchronize()
+
+    def exchange_ms(self):
+        return None
+
+    def barrier(self):
+        self.torch.cuda.synchronize()
+
+    def reduce_sum(self, values):
+        return list(values)
+
+    def reduce_max(self, values):
+        return list(values)
+
+    def gather_rows(self, row):
+        return [list(row)]
+
+    def close(self):
+        self.r.close()
+
+
+class OneProcessManyGpus:
+    """`python bench.py --gpus N` without a launcher: srt_comm_init_all -- one process, N contexts, ncclCommInitAll, one HIP stream per
+    device; srt_render_frame_multi enqueues the N render kernels, ONE grouped ncclGather and the scatter.  If the communicator
+    cannot be formed, or its verification frame differs from a single-context render, the exchange falls back to device-to-device
+    copies through torch (same bytes, same links, no collective) and the JSON says so."""
+    launch_mode = "one process drives all GPUs (srt_comm_init_all: ncclCommInitAll, one HIP stream per device)"
+
+    def __init__(self, srt, torch, devices):
+        self.srt, self.torch, self.devices = srt, torch, list(devices)
+        self.world, self.rank = len(devices), 0
+        self.comm, self.gather_check = None, None
+        try:
+            self.comm = srt.Comm.init_all(self.devices)
+            self.local = self.comm.renderers
+            self.root = self.comm.root
+            self.gather_via = "srt_render_frame_multi (ncclGather inside libsrt_hip.so, communicator from srt_comm_init_all)"
+        except Exception as e:      # noqa: BLE001 -- any failure here must not lose the measurement
+            log("srt_comm_init_all failed (%r); exchanging the tile buffers with device-to-device copies instead" % (e,))
+            self._fallback("library communicator unavailable: %r" % (e,))
+
+    def _fallback(self, why):
+        if self.comm is not None:
+            self.comm.close()
+            self.comm = None
+        self.local = [self.srt.Renderer(d) for d in self.devices]
+        for k, r in enumerate(self.local):
+            r.set_partition(k, self.world)
+        self.root = self.local[0]
+        self._staging, self._gathered = None, None
+        self.gather_via = "device-to-device copies through torch (%s)" % why
+
+    def upload(self, scene, cam):
+        self._scene, self._cam = scene, cam
+        if self.comm is not None:
+            self.comm.upload_scene(scene); self.comm.set_camera(cam)
+        else:
+            for r in self.local:
+                r.upload_scene(scene); r.set_camera(cam)
+
+    def init_params(self, W, H, spp, depth):
+        self._depth = depth
+        if self.comm is not None:
+            self.comm.init_device_params(W, H, spp, depth, 1984)
+        else:
+            for r in self.local:
+                r.init_device_params(W, H, spp, depth, 1984)
+
+    def set_count(self, on):
+        for r in self.local:
+            r.set_count_traversal(on)
+
+    def frame(self, W, H):
+        if self.comm is not None:
+            self.comm.render_frame(W, H, 0, 0)
+            self.comm.synchronize()
+            return
+        torch = self.torch
+        for r in self.local:
+            r.render_chunk(W, H, 0, 0, None)          # asynchronous: the devices render side by side
+        _, n_floats, _, _ = self.local[0].tile_buffer()
+        if self._staging is None or self._staging[0].numel() != n_floats:
+            self._staging = [torch.empty(n_floats, dtype=torch.float32, device="cuda:%d" % d) for d in self.devices]
+            self._gathered = torch.empty((self.world, n_floats), dtype=torch.float32, device="cuda:%d" % self.devices[0])
+        for r, t in zip(self.local, self._staging):
+            r.copy_tile_buffer(t.data_ptr(), None)
+            r.synchronize()
+        for k, t in enumerate(self._staging):
+            self._gathered[k].copy_(t)
+        torch.cuda.synchronize(self.devices[0])
+        self.root.scatter_tiles(self._gathered.data_ptr(), None)
+        self.root.synchronize()
+
+    def verify(self, W, H, depth, spp=8):
+        """one cheap frame through the communicator against the same frame on ONE context: the assembled framebuffers must be equal
+        (the image does not depend on the partition).  A difference or an error moves the exchange to the fallback."""
+        if self.comm is None:
+            return
+        ok, note = True, None
+        try:
+            self.init_params(W, H, spp, depth)
+            self.frame(W, H)
+            got = checksum_of(self.root)
+            solo = self.srt.Renderer(self.devices[0])
+            try:
+                img = self.srt.render_image(self._scene, self._cam, W, H, spp, depth, renderer=solo)
+                want = int(sum(int(p.astype("int64").sum()) for p in img["fb"]))
+            finally:
+                solo.close()
+            if got != want:
+                ok, note = False, "framebuffer checksum %d != single-context %d" % (got, want)
+        except Exception as e:      # noqa: BLE001
+            ok, note = False, "error %r" % (e,)
+        if ok:
+            self.gather_check = ("verified: %d-spp frame through the library's ncclGather (%d ranks) == the same frame rendered by one context "
+                                 "(framebuffer checksum)" % (spp, self.world))
+        else:
+            log("library gather FAILED its verification frame (%s)" % note)
+            self._fallback("library gather FAILED its verification frame: %s" % note)
+            self.upload(self._scene, self._cam)
+            self.gather_check = "failed: " + note
+
+    def exchange_ms(self):
+        return self.comm.last_gather_ms() if self.comm is not None else None
+
+    def barrier(self):
+        for d in self.devices:
+            self.torch.cuda.synchronize(d)
+
+    def reduce_sum(self, values):
+        return list(values)
+
+    def reduce_max(self, values):
+        return list(values)
+
+    def gather_rows(self, row):
+        raise NotImplementedError      # per-rank rows are built from self.local directly
+
+    def close(self):
+        if self.comm is not None:
+            self.comm.close()
+        else:
+            for r in self.local:
+                r.close()
+
+
+class OneProcessPerGpu:
+    """torch.distributed.run: this process is ONE rank.  The exchange is the library's communicator (srt_comm_init_rank; the id
+    travels through torch.distributed), verified against torch.distributed.gather before it carries a measurement; fallback:
+    torch.distributed.gather."""
+    launch_mode = "one process per GPU (torch.distributed.run, srt_comm_init_rank)"
+
+    def __init__(self, srt, torch, dist, tiles, rank, world, local_rank, torch_gather=False, rehearse_gloo=False):
+        self.srt, self.torch, self.dist, self.tiles = srt, torch, dist, tiles
+        self.rank, self.world, self.rehearse = rank, world, rehearse_gloo
+        self.red_dev = "cpu" if rehearse_gloo else "cuda"       # where the small statistics tensors of the reductions live
+        self.r = srt.Renderer(local_rank)
+        self.r.set_partition(rank, world)
+        self.local, self.root = [self.r], (self.r if rank == 0 else None)
+        self.stream = torch.cuda.current_stream().cuda_stream
+        self.comm, self.gather_check, self._local_tiles = None, None, None
+        self.gather_via = "torch.distributed gather"
+        if rehearse_gloo:
+            self.launch_mode = "REHEARSAL: one process per rank on ONE GPU, torch.distributed on gloo (never used for reported numbers)"
+        if torch_gather or rehearse_gloo:
+            return
+        # (1) a cheap LOCAL precheck agreed on by all ranks before anybody enters the collective ncclCommInitRank: a rank
+        # that cannot load RCCL must not leave the others waiting in the bootstrap
+        pre = torch.tensor([1.0 if srt.Comm.available() else 0.0], device=self.red_dev)
+        dist.all_reduce(pre, op=dist.ReduceOp.MIN)
+        if float(pre[0]) > 0.5:
+            ident = [None]
+            if rank == 0:
+                try:
+                    ident[0] = srt.Comm.unique_id()
+                except Exception as e:      # noqa: BLE001 -- any failure here must not lose the measurement
+                    log("library communicator unavailable (%r); using torch.distributed for the gather" % (e,))
+            dist.broadcast_object_list(ident, src=0)      # every rank takes part, whatever rank 0 got
+            if ident[0] is not None:
+                try:
+                    self.comm = srt.Comm.init_rank(self.r, ident[0], rank, world)
+                except Exception as e:      # noqa: BLE001
+                    log("rank %d: srt_comm_init_rank failed (%r); using torch.distributed for the gather" % (rank, e))
+                    self.comm = None
+            ok = torch.tensor([1.0 if self.comm is not None else 0.0], device=self.red_dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if float(ok[0]) < 0.5 and self.comm is not None:      # every rank or none
+                self.comm.close()
+                self.comm = None
+        else:
+            log("rank %d: RCCL not loadable on every rank; using torch.distributed for the gather" % rank)
+        if self.comm is None:
+            self.gather_via = "torch.distributed gather (library communicator unavailable)"
+        else:
+            self.gather_via = "srt_render_frame_multi (ncclGather inside libsrt_hip.so, communicator from srt_comm_init_rank)"
+            # every rank must gather the same number of planes (the library checks it once more on the first frame)
+            planes = torch.tensor([3.0, -3.0], device=self.red_dev)
+            dist.all_reduce(planes, op=dist.ReduceOp.MAX)
+            assert float(planes[0]) == 3.0 and float(planes[1]) == -3.0
+
+    def upload(self, scene, cam):
+        self.r.upload_scene(scene); self.r.set_camera(cam); self.r.set_partition(self.rank, self.world)
+
+    def init_params(self, W, H, spp, depth):
+        self.r.init_device_params(W, H, spp, depth, 1984)
+
+    def set_count(self, on):
+        self.r.set_count_traversal(on)
+
+    def _frame_torch_gather(self, W, H):
+        torch, r = self.torch, self.r
+        r.render_chunk(W, H, 0, 0, self.stream)
+        _, n_floats, _, _ = r.tile_buffer()          # the exchange unit: the quantised framebuffer of this rank's tiles (12 B / pixel)
+        if self._local_tiles is None or self._local_tiles.numel() != n_floats:
+            self._local_tiles = torch.empty(n_floats, dtype=torch.float32, device="cuda")
+        r.copy_tile_buffer(self._local_tiles.data_ptr(), self.stream)        # stream-ordered D2D into the tensor RCCL sends
+        if self.rehearse:
+            torch.cuda.current_stream().synchronize()
+            gh = self.tiles.gather_tiles(self._local_tiles.cpu(), self.rank, self.world)
+            g = gh.cuda() if self.rank == 0 else None
+        else:
+            g = self.tiles.gather_tiles(self._local_tiles, self.rank, self.world)      # the single collective of the path
+        if self.rank == 0:
+            r.scatter_tiles(g.data_ptr(), self.stream)
+        torch.cuda.synchronize()          # (g is a temporary)
+
+    def frame(self, W, H):
+        if self.comm is not None:
+            self.comm.render_frame(W, H, 0, 0)           # render + ONE ncclGather + scatter on rank 0, all enqueued by the library
+            self.comm.synchronize()
+        else:
+            self._frame_torch_gather(W, H)
+
+    def verify(self, W, H, depth, spp=8):
+        """the library's RCCL gather against torch.distributed.gather on one cheap frame, before it carries the measurement: rank 0
+        compares the assembled framebuffers; any difference or error falls back to torch.distributed.gather and the JSON says so."""
+        if self.comm is None:
+            return
+        torch, dist = self.torch, self.dist
+        verdict = 1.0
+        try:
+            self.init_params(W, H, spp, depth)
+            self._frame_torch_gather(W, H)
+            want = checksum_of(self.r) if self.rank == 0 else 0
+            self.init_params(W, H, spp, depth)
+            self.frame(W, H)
+            got = checksum_of(self.r) if self.rank == 0 else 0
+            if self.rank == 0 and got != want:
+                verdict = 0.0
+                log("library gather framebuffer checksum %d != torch gather %d" % (got, want))
+        except Exception as e:      # noqa: BLE001
+            verdict = 0.0
+            log("rank %d: library gather failed in the verification frame (%r)" % (self.rank, e))
+        v = torch.tensor([verdict], device=self.red_dev)
+        dist.all_reduce(v, op=dist.ReduceOp.MIN)
+        if float(v[0]) < 0.5:
+            self.comm.close()
+            self.comm = None
+            self.gather_via = "torch.distributed gather (library gather FAILED its verification frame)"
+            self.gather_check = "failed"
+        else:
+            self.gather_check = ("verified: %d-spp frame through the library's ncclGather == the same frame through torch.distributed.gather "
+                                 "(framebuffer checksum on rank 0)" % spp)
+
+    def exchange_ms(self):
+        return self.comm.last_gather_ms() if self.comm is not None else None
+
+    def barrier(self):
+        self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def _reduce(self, values, op):
+        t = self.torch.tensor([float(v) for v in values], dtype=self.torch.float64, device=self.red_dev)
+        self.dist.all_reduce(t, op=op)
+        return t.tolist()
+
+    def reduce_sum(self, values):
+        return self._reduce(values, self.dist.ReduceOp.SUM)
+
+    def reduce_max(self, values):
+        return self._reduce(values, self.dist.ReduceOp.MAX)
+
+    def gather_rows(self, row):
+        t = self.torch.zeros((self.world, len(row)), dtype=self.torch.float64, device=self.red_dev)
+        for k, v in enumerate(row):
+            t[self.rank, k] = float(v)
+        self.dist.all_reduce(t)
+        return t.tolist()
+
+    def close(self):
+        if self.comm is not None:
+            self.comm.close()
+        self.r.close()
+
+
+def traversal_counts(job, W, H, depth):
+    """V, T (node records / triangle tests per ray), rays per path and the share of NaN-direction rays from the instrumented kernel
+    at 4 spp, all ranks, outside any timed region"""
+    job.init_params(W, H, 4, depth)
+    job.set_count(True)
+    job.frame(W, H)
+    loc = [0.0] * 5
+    for r in job.local:
+        st = r.stats()
+        for k, v in enumerate((st["rays"], st["node_visits"], st["tri_tests"], st["paths"], st["util"][2])):
+            loc[k] += float(v)
+    job.set_count(False)
+    rays_c, V_c, T_c, paths_c, nan_c = job.reduce_sum(loc)
+    V, T = V_c / rays_c, T_c / rays_c
+    return dict(V=V, T=T, rays_per_path=rays_c / paths_c, nan_share=nan_c / rays_c, b_ray=V * NODE_BYTES + T * TRI_BYTES + MAT_BYTES)
+
+
+def timed_frames(job, W, H, spp, depth, steps, warmup, label=""):
+    """`warmup` untimed steps, then EXACTLY `steps` timed ones between two barriers; one step = seed the per-pixel RNG streams
+    (init_device_params, rendering.cu:320-335), render, assemble the framebuffer on rank 0 -- every step produces the same image.
+    Returns elapsed (max over ranks), total rays, and per-rank rows [kernel ms, rays per frame, exchange ms after own kernel]."""
+    def step():
+        job.init_params(W, H, spp, depth)
+        job.frame(W, H)
+
+    for k in range(warmup):
+        t0 = time.time()
+        step()
+        job.barrier()
+        if job.rank == 0:
+            log("%swarmup %d/%d: %.2f s" % (label, k + 1, warmup, time.time() - t0))
+    job.barrier()
+    t0 = time.perf_counter()
+    n_local = len(job.local)
+    kernel_ms, rays, gather_ms = [[] for _ in range(n_local)], [0] * n_local, []
+    for k in range(steps):
+        ts = time.time()
+        step()
+        # per-step kernel time from the HIP events the library records on the launch stream around the render kernel alone
+        for i, r in enumerate(job.local):
+            kernel_ms[i].append(r.last_kernel_ms())
+            rays[i] += r.stats()["rays"]
+        g = job.exchange_ms()
+        if g is not None:
+            gather_ms.append(g)
+        if job.rank == 0:
+            log("%sstep %d/%d: kernel %.1f ms, wall %.2f s" % (label, k + 1, steps, max(x[-1] for x in kernel_ms), time.time() - ts))
+    job.barrier()
+    elapsed = time.perf_counter() - t0
+    n = max(steps, 1)
+    mean_k = [sum(x) / max(len(x), 1) for x in kernel_ms]
+    mean_g = sum(gather_ms) / len(gather_ms) if gather_ms else 0.0
+    total_rays = job.reduce_sum([float(sum(rays))])[0]
+    elapsed = job.reduce_max([elapsed])[0]
+    if n_local == job.world:          # this process sees every rank
+        rows = [[mean_k[i], rays[i] / n, mean_g] for i in range(n_local)]
+    else:
+        rows = job.gather_rows([mean_k[0], rays[0] / n, mean_g])
+    return dict(elapsed=elapsed, total_rays=total_rays, rows=rows, kms=max(x[0] for x in rows), rays_rank0=rows[0][1])
+
+
+def lane_ops_entry(scene_id):
+    for f in LANE_OPS_FILES:
+        try:
+            e = json.load(open(f)).get("scene_%d" % scene_id)
+        except Exception:      # noqa: BLE001
+            e = None
+        if e is not None:
+            return e, os.path.relpath(f, ROOT)
+    return None, None
+
+
+def kernel_tie(renderer, entry, lib_path):
+    """which kernel variant the uploaded scene launches, the hash of its machine code in the LOADED library (tools/kernel_id.py: the
+    kernel's bytes in the gfx950 code object; for PMC entries that predate it, the hash of the build's ISA listing), and how an
+    imported PMC entry relates to it"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_id
+    plan = renderer.launch_plan()
+    nr, ac = int(plan["narrow_refs"]), int(plan["all_cached"])
+    variant = "render_kernel<0,%d,%d>" % (nr, ac)
+    code_hash, code_note = kernel_id.code_hash(lib_path, nr, ac)
+    isa_hash, isa_note = kernel_id.isa_hash(nr, ac)
+    hashes = {"code_sha256": code_hash, "isa_listing_sha256": isa_hash}
+    tie = None
+    if entry is not None:
+        if entry.get("kernel_code_sha256") is not None:
+            mine, theirs, what = code_hash, entry["kernel_code_sha256"], "machine code in the loaded library"
+            note = code_note
+        else:
+            mine, theirs, what = isa_hash, entry.get("kernel_isa_sha256"), "ISA listing of the build"
+            note = isa_note
+        if mine is None:
+            tie = "UNVERIFIED (%s)" % note
+        elif theirs is None:
+            tie = "UNVERIFIED (the imported PMC pass predates the hash tie)"
+        elif theirs == mine:
+            tie = "current (PMC pass taken on this kernel binary: %s sha256 %s)" % (what, mine[:16])
+        else:
+            tie = "STALE (PMC pass was taken on kernel %s, this library is %s: %s)" % (theirs[:16], mine[:16], what)
+    return plan, variant, hashes, tie
+
+
+def small_roofline(renderer, scene_id, rays_per_launch, kms, lib_path):
+    """frac_arch of a secondary workload: imported lane-ops per ray of ITS kernel variant / scene (hash-tied) x live rays / live kernel time"""
+    entry, entry_file = lane_ops_entry(scene_id)
+    plan, variant, hashes, tie = kernel_tie(renderer, entry, lib_path)
+    out = {"kernel": variant, "kernel_code_sha256": hashes["code_sha256"], "kernel_isa_sha256": hashes["isa_listing_sha256"], "frac_arch": None, "achieved_source": None}
+    if entry is not None:
+        ach = rays_per_launch * entry["lane_ops_per_ray"] / (kms * 1e-3) / 1e9
+        out.update(achieved=ach, unit="G lane-op/s", frac_arch=ach / ARCH_PEAK_GLANEOPS, lanes_per_valu_instruction=entry.get("lanes_per_valu_instruction"),
+                   achieved_source="%s: %.1f useful VALU lane-ops per ray IMPORTED from %s (kernel %s) x live rays / live kernel time" %
+                                   (tie, entry["lane_ops_per_ray"], entry_file, entry.get("kernel", "?")))
+    else:
+        out["achieved_source"] = "no PMC pass of scene %d under profiles/" % scene_id
+    return out
+
+
+def secondary_workload(srt, job, scene_id, bvh, W, H, spp, depth, with_roofline=True):
+    """one frame of another BASELINE configuration on the same ranks, outside the headline's timed region"""
+    t_build = time.time()
+    scene = srt.Scene.builtin(scene_id, 0).build_bvh(bvh, 1984)
+    cam = scene.default_camera(W, H)
+    job.upload(scene, cam)
+    t_build = time.time() - t_build
+    tc = traversal_counts(job, W, H, depth)
+    tf = timed_frames(job, W, H, spp, depth, 1, 0, label="[%s %dx%d %d spp] " % (SCENE_NAMES.get(scene_id, scene_id), W, H, spp))
+    rec = None
+    if job.rank == 0:
+        rec = {"workload": "%s (%d tris, %d BVH nodes), %dx%d, %d spp, depth %d" % (SCENE_NAMES.get(scene_id, "scene %d" % scene_id), scene.n_tris, scene.n_nodes, W, H, spp, depth),
+               "scene_id": scene_id, "bvh": "SAH" if bvh == 1 else "reference builder",
+               "value": tf["total_rays"] / tf["elapsed"] / 1e6, "unit": "Mray/s", "frames": 1, "ms": tf["elapsed"] * 1e3, "kernel_ms": tf["kms"],
+               "rays": tf["total_rays"], "V": tc["V"], "T": tc["T"], "rays_per_path": tc["rays_per_path"],
+               "nan_direction_rays_pct": 100.0 * tc["nan_share"], "algorithmic_bytes_per_ray": tc["b_ray"],
+               "fb_checksum": checksum_of(job.root), "scene_build_s": t_build}
+        if job.world > 1:
+            rec["per_rank_kernel_ms"] = [round(x[0], 3) for x in tf["rows"]]
+            rec["per_rank_rays"] = [int(x[1]) for x in tf["rows"]]
+        if with_roofline and job.world == 1:
+            rec["roofline"] = small_roofline(job.root, scene_id, tf["rays_rank0"], tf["kms"], srt.binding.LIB_PATH)
+            rec["frac_arch"] = rec["roofline"]["frac_arch"]
+            rec["achieved_source"] = rec["roofline"]["achieved_source"]
+    return rec
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -181,262 +663,104 @@ def main():
     ap.add_argument("--bvh", type=int, default=1)              # SRT_BVH_SAH for the synthetic scenes
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-calibration", action="store_true", help="skip the issue-rate microkernel and the copy-rate measurement (profiling passes)")
-    ap.add_argument("--torch-gather", action="store_true", help="N > 1: gather through torch.distributed instead of the library's RCCL communicator")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip cfg 2 / cfg 4 / cfg 5's scene at 512 spp (N = 1 block `other_configs`)")
+    ap.add_argument("--cfg5-spp", type=int, default=4096, help="samples of the cfg 5 sub-record (BASELINE: 4096); 0 = skip it")
+    ap.add_argument("--cfg5-size", default="3840x2160", help="image size of the cfg 5 sub-record (BASELINE: 3840x2160)")
+    ap.add_argument("--torch-gather", action="store_true", help="one process per GPU: gather through torch.distributed instead of the library's RCCL communicator")
     ap.add_argument("--rehearse-gloo", action="store_true",
-                    help="rehearsal of the N > 1 control flow on ONE GPU: every rank uses cuda:0, torch.distributed runs on gloo and the gather goes through host memory (never used for reported numbers)")
+                    help="rehearsal of the process-per-GPU control flow on ONE GPU: every rank uses cuda:0, torch.distributed runs on gloo and the gather goes through host memory (never used for reported numbers)")
     args = ap.parse_args()
 
     import torch
-    import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+    launcher = "WORLD_SIZE" in os.environ and world > 1
+    if launcher and args.gpus != world:
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
-    if args.rehearse_gloo or local_rank >= torch.cuda.device_count():      # (launcher restricted each rank's visible devices to its own GPU)
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    if world > 1:
+    n_dev = torch.cuda.device_count()
+
+    import __graft_entry__
+    srt = __graft_entry__._pkg()
+
+    # ---- the ranks --------------------------------------------------------------------------------------------------------
+    if launcher:
+        import torch.distributed as dist
+        from importlib import import_module
+        tiles = import_module("cuda-spectral-ray-tracer_amd.tiles")
+        if args.rehearse_gloo or local_rank >= n_dev:      # (launcher restricted each rank's visible devices to its own GPU)
+            local_rank = 0
+        torch.cuda.set_device(local_rank)
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.rehearse_gloo:
             dist.init_process_group(backend="gloo")
         else:
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    red_dev = "cpu" if args.rehearse_gloo else "cuda"       # where the small statistics tensors of the reductions live
-
-    import __graft_entry__
-    srt = __graft_entry__._pkg()
-    from importlib import import_module
-    tiles = import_module("cuda-spectral-ray-tracer_amd.tiles")
+        job = OneProcessPerGpu(srt, torch, dist, tiles, rank, world, local_rank, args.torch_gather, args.rehearse_gloo)
+    elif args.gpus > 1:
+        # no launcher: this process drives all N GPUs.  (SRT_COMM_TEST_SAME_DEVICE=1 with the test transport of tests/cpp/mock_rccl.cpp
+        # puts the N ranks on device 0: the single-GPU rehearsal of this path, tests/test_gpu_parity.py)
+        same = os.environ.get("SRT_COMM_TEST_SAME_DEVICE") == "1" and os.environ.get("SRT_RCCL_LIB")
+        if not same and args.gpus > n_dev:
+            raise SystemExit("bench.py --gpus %d: only %d GPUs are visible to this process" % (args.gpus, n_dev))
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(0)
+        world = args.gpus
+        job = OneProcessManyGpus(srt, torch, [0] * world if same else list(range(world)))
+        if same:
+            job.launch_mode += " -- REHEARSAL: all ranks on device 0 over the test transport (never used for reported numbers)"
+    else:
+        torch.cuda.set_device(local_rank if local_rank < n_dev else 0)
+        job = OneGpu(srt, torch, torch.cuda.current_device())
 
     # ---- inputs, resident in HBM before the timed region ------------------------------------------------
     scene = srt.Scene.builtin(args.scene, 0).build_bvh(args.bvh, 1984)
     W, H = args.width, args.height
     cam = scene.default_camera(W, H)
-    r = srt.Renderer(local_rank)
-    r.upload_scene(scene)
-    r.set_camera(cam)
-    r.set_partition(rank, world)
-    stream = torch.cuda.current_stream().cuda_stream
+    job.upload(scene, cam)
 
-    # ---- the exchange path: the library's own RCCL communicator (srt_comm_*, behind the C-ABI); torch.distributed only
-    # carries the 128-byte communicator id, the barriers and the statistics.  If the communicator cannot be formed the
-    # gather falls back to torch.distributed (same bytes, same xGMI links) and the JSON says so.
-    comm, gather_via, gather_check = None, "none (1 GPU)", None
-    if world > 1:
-        gather_via = "torch.distributed gather"
-        if not args.torch_gather and not args.rehearse_gloo:
-            # (1) a cheap LOCAL precheck agreed on by all ranks before anybody enters the collective ncclCommInitRank: a rank
-            # that cannot load RCCL must not leave the others waiting in the bootstrap
-            pre = torch.tensor([1.0 if srt.Comm.available() else 0.0], device=red_dev)
-            dist.all_reduce(pre, op=dist.ReduceOp.MIN)
-            if float(pre[0]) > 0.5:
-                ident = [None]
-                if rank == 0:
-                    try:
-                        ident[0] = srt.Comm.unique_id()
-                    except Exception as e:      # noqa: BLE001 -- any failure here must not lose the measurement
-                        log("library communicator unavailable (%r); using torch.distributed for the gather" % (e,))
-                dist.broadcast_object_list(ident, src=0)      # every rank takes part, whatever rank 0 got
-                if ident[0] is not None:
-                    try:
-                        comm = srt.Comm.init_rank(r, ident[0], rank, world)
-                        gather_via = "srt_render_frame_multi (ncclGather inside libsrt_hip.so)"
-                    except Exception as e:      # noqa: BLE001
-                        log("rank %d: srt_comm_init_rank failed (%r); using torch.distributed for the gather" % (rank, e))
-                        comm = None
-                ok = torch.tensor([1.0 if comm is not None else 0.0], device=red_dev)
-                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-                if float(ok[0]) < 0.5 and comm is not None:      # every rank or none
-                    comm.close()
-                    comm = None
-            else:
-                log("rank %d: RCCL not loadable on every rank; using torch.distributed for the gather" % rank)
-            if comm is None:
-                gather_via = "torch.distributed gather (library communicator unavailable)"
-
-    # ---- V, T (node records / triangle tests per ray) from the instrumented kernel, outside the timed region
-    r.init_device_params(W, H, 4, args.depth, 1984)
-    r.set_count_traversal(True)
-    r.render_chunk(W, H, 0, 0, stream)
-    st = r.stats()
-    cnt = torch.tensor([st["rays"], st["node_visits"], st["tri_tests"], st["paths"], st["util"][2]], dtype=torch.float64, device=red_dev)
-    if world > 1:
-        dist.all_reduce(cnt)
-    rays_c, V_c, T_c, paths_c, nan_c = [float(x) for x in cnt.tolist()]
-    V, T, rays_per_path = V_c / rays_c, T_c / rays_c, rays_c / paths_c
-    b_ray = V * NODE_BYTES + T * TRI_BYTES + MAT_BYTES
-    r.set_count_traversal(False)
+    # ---- V, T from the instrumented kernel, outside the timed region
+    tc = traversal_counts(job, W, H, args.depth)
 
     # ---- calibration of the roofs, outside the timed region (rank 0, N = 1) -------------------------------------------
     calib, copy_gbs = None, None
-    if rank == 0 and world == 1 and not args.no_calibration:
-        calib = r.calibrate(0, 4, 40000)            # v_add_f32, 4 waves / SIMD, one workgroup per CU
+    if job.world == 1 and not args.no_calibration:
+        calib = job.root.calibrate(0, 4, 40000)            # v_add_f32, 4 waves / SIMD, one workgroup per CU
         copy_gbs = measure_hbm_copy_gbs(torch)
         log("calibration: %.1f G wave-instr/s (%.3f / cycle / SIMD at %.2f GHz; wave Mcycles min/mean/max %.2f/%.2f/%.2f); copy %.0f GB/s" %
             (calib["instr_per_s"] / 1e9, calib["instr_per_cycle_per_simd"], calib["clock_ghz"], calib["wave_cycles_min"] / 1e6,
              calib["wave_cycles_mean"] / 1e6, calib["wave_cycles_max"] / 1e6, copy_gbs))
 
-    r.init_device_params(W, H, args.spp, args.depth, 1984)
+    # ---- the exchange path is checked on one cheap frame before it carries a measurement (RCCL has carried this path on mock
+    # transports and one-rank worlds only: no multi-GPU hardware has run it before the first driver run that has such a node)
+    if job.world > 1:
+        job.verify(W, H, args.depth)
 
-    local_tiles = None      # torch-owned staging tensor for the torch.distributed gather
+    # ---- the timed region --------------------------------------------------------------------------------------------------
+    tf = timed_frames(job, W, H, args.spp, args.depth, args.steps, args.warmup)
+    elapsed, total_rays, kms = tf["elapsed"], tf["total_rays"], tf["kms"]
 
-    def frame_torch_gather():
-        nonlocal local_tiles
-        r.render_chunk(W, H, 0, 0, stream)
-        _, n_floats, _, _ = r.tile_buffer()          # the exchange unit: the quantised framebuffer of this rank's tiles (12 B / pixel)
-        if local_tiles is None or local_tiles.numel() != n_floats:
-            local_tiles = torch.empty(n_floats, dtype=torch.float32, device="cuda")
-        r.copy_tile_buffer(local_tiles.data_ptr(), stream)        # stream-ordered D2D into the tensor RCCL sends
-        if args.rehearse_gloo:
-            torch.cuda.current_stream().synchronize()
-            gh = tiles.gather_tiles(local_tiles.cpu(), rank, world)
-            g = gh.cuda() if rank == 0 else None
-        else:
-            g = tiles.gather_tiles(local_tiles, rank, world)      # the single collective of the path
-        if rank == 0:
-            r.scatter_tiles(g.data_ptr(), stream)
-            if args.rehearse_gloo:
-                torch.cuda.current_stream().synchronize()          # g is a temporary
-
-    def frame_library_gather():
-        comm.render_frame(W, H, 0, 0)           # render + ONE ncclGather + scatter on rank 0, all enqueued by the library
-        comm.synchronize()
-
-    def checksum_rank0():
-        if rank != 0:
-            return 0
-        fb = r.read_fb()
-        return int(sum(int(p.astype("int64").sum()) for p in fb))
-
-    # (2) the library's RCCL gather has been exercised on ONE GPU only (world 1 returns before the gather): before it carries the
-    # measurement, one cheap frame (8 spp) goes through BOTH exchange paths and rank 0 compares the assembled framebuffers; any
-    # difference or error falls back to the torch.distributed gather (validated on hardware in round 1) and the JSON says so.
-    if comm is not None:
-        verdict = 1.0
-        try:
-            r.init_device_params(W, H, 8, args.depth, 1984)
-            frame_torch_gather(); torch.cuda.synchronize()
-            want = checksum_rank0()
-            r.init_device_params(W, H, 8, args.depth, 1984)
-            frame_library_gather()
-            got = checksum_rank0()
-            if rank == 0 and got != want:
-                verdict = 0.0
-                log("library gather framebuffer checksum %d != torch gather %d" % (got, want))
-        except Exception as e:      # noqa: BLE001
-            verdict = 0.0
-            log("rank %d: library gather failed in the verification frame (%r)" % (rank, e))
-        v = torch.tensor([verdict], device=red_dev)
-        dist.all_reduce(v, op=dist.ReduceOp.MIN)
-        if float(v[0]) < 0.5:
-            comm.close()
-            comm = None
-            gather_via = "torch.distributed gather (library gather FAILED its verification frame)"
-            gather_check = "failed"
-        else:
-            gather_check = "verified: 8-spp frame through the library's ncclGather == the same frame through torch.distributed.gather (framebuffer checksum on rank 0)"
-
-    def step():
-        # one step = one complete frame: seed the per-pixel RNG streams (init_device_params, rendering.cu:320-335), render,
-        # assemble the framebuffer on rank 0.  Every step therefore produces the same image (fb_checksum).
-        r.init_device_params(W, H, args.spp, args.depth, 1984)
-        if world == 1:
-            r.render_chunk(W, H, 0, 0, stream)
-            r.scatter_tiles(None, stream)
-        elif comm is not None:
-            frame_library_gather()
-        else:
-            frame_torch_gather()
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for k in range(args.warmup):
-        t0 = time.time()
-        step()
-        barrier()
-        if rank == 0:
-            log("warmup %d/%d: %.2f s" % (k + 1, args.warmup, time.time() - t0))
-
-    barrier()
-    t0 = time.perf_counter()
-    kernel_ms, gather_ms, rays_local = [], [], 0
-    for k in range(args.steps):
-        ts = time.time()
-        step()
-        # per-step kernel time from the HIP events the library records on the launch stream; reading it waits for the
-        # kernel only, and is inside the timed region on purpose (it costs one event sync).
-        kernel_ms.append(r.last_kernel_ms())
-        if comm is not None:
-            gather_ms.append(comm.last_gather_ms())
-        rays_local += r.stats()["rays"]
-        if rank == 0:
-            log("step %d/%d: kernel %.1f ms, wall %.2f s" % (k + 1, args.steps, kernel_ms[-1], time.time() - ts))
-    barrier()
-    elapsed = time.perf_counter() - t0
-
-    my_kms = sum(kernel_ms) / max(len(kernel_ms), 1)
-    my_gms = sum(gather_ms) / max(len(gather_ms), 1) if gather_ms else 0.0
-    tot = torch.tensor([float(rays_local), elapsed, my_kms], dtype=torch.float64, device=red_dev)
-    per_rank = None
-    if world > 1:
-        rays_t = tot[0:1].clone(); dist.all_reduce(rays_t)
-        mx = tot[1:3].clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-        total_rays, elapsed, kms = float(rays_t[0]), float(mx[0]), float(mx[1])
-        # per-rank diagnosis of the first real multi-GPU lines: render-kernel ms, rays, and the time between the end of the rank's
-        # kernel and the end of the exchange (gather + waiting for the slowest rank [+ scatter on rank 0])
-        mine = torch.zeros((world, 3), dtype=torch.float64, device=red_dev)
-        mine[rank, 0], mine[rank, 1], mine[rank, 2] = my_kms, float(rays_local) / max(args.steps, 1), my_gms
-        dist.all_reduce(mine)
-        per_rank = {"kernel_ms": [round(float(x), 3) for x in mine[:, 0].tolist()], "rays_per_frame": [int(x) for x in mine[:, 1].tolist()],
-                    "exchange_ms_after_own_kernel": [round(float(x), 3) for x in mine[:, 2].tolist()] if comm is not None else None}
-    else:
-        total_rays, elapsed, kms = float(tot[0]), float(tot[1]), float(tot[2])
-
-    if rank == 0:
+    out = None
+    if job.rank == 0:
         steps = max(args.steps, 1)
-        headline = world == 1 and (args.scene, W, H, args.spp, args.depth, args.bvh) == (100, 1920, 1080, 1024, 16, 1)
+        headline = job.world == 1 and (args.scene, W, H, args.spp, args.depth, args.bvh) == (100, 1920, 1080, 1024, 16, 1)
         mray = total_rays / elapsed / 1e6
-        rays_per_launch_rank0 = rays_local / steps
+        rays_per_launch_rank0 = tf["rays_rank0"]
+        b_ray = tc["b_ray"]
         # ---- roofline of the dominant kernel (render_kernel) on this rank -------------------------------------------
-        sys.path.insert(0, os.path.join(ROOT, "tools"))
-        import kernel_id
-        plan = r.launch_plan()
-        variant = "render_kernel<0,%d,%d>" % (int(plan["narrow_refs"]), int(plan["all_cached"]))
-        my_hash, hash_note = kernel_id.isa_hash(int(plan["narrow_refs"]), int(plan["all_cached"]))
-        entry, entry_file = None, None
-        for f in LANE_OPS_FILES:
-            try:
-                e = json.load(open(f)).get("scene_%d" % args.scene)
-            except Exception:      # noqa: BLE001
-                e = None
-            if e is not None:
-                entry, entry_file = e, os.path.relpath(f, ROOT)
-                break
+        entry, entry_file = lane_ops_entry(args.scene)
+        plan, variant, hashes, tie = kernel_tie(job.root, entry, srt.binding.LIB_PATH)
         roof = {"bound": "valu-issue", "achieved": None, "peak": None, "unit": "G lane-op/s", "frac": None, "frac_arch": None, "traffic": None,
                 "peak_arch": ARCH_PEAK_GLANEOPS,
                 "peak_arch_source": "256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz (MI355X_MICROARCH.md: a wave64 VALU instruction issues over 2 cycles; 157.3 TFLOP/s fp32 FMA / 2)"}
-        roof["kernel_isa_sha256"] = my_hash
+        roof["kernel_code_sha256"], roof["kernel_isa_sha256"] = hashes["code_sha256"], hashes["isa_listing_sha256"]
         roof["kernel"] = variant + ", %d waves per CU, %d of the inner records in LDS" % (plan["waves_per_cu"], plan["n_cached"])
+        roof["library"] = os.path.relpath(srt.binding.LIB_PATH, ROOT)
         if entry is not None:
             lane_ops_per_ray = entry["lane_ops_per_ray"]
-            pmc_hash = entry.get("kernel_isa_sha256")
-            if my_hash is None:
-                tie = "UNVERIFIED (%s)" % hash_note
-            elif pmc_hash is None:
-                tie = "UNVERIFIED (the imported PMC pass predates the hash tie)"
-            elif pmc_hash == my_hash:
-                tie = "current (PMC pass taken on this kernel binary: ISA sha256 %s)" % my_hash[:16]
-            else:
-                tie = "STALE (PMC pass was taken on kernel ISA %s, this library is %s)" % (pmc_hash[:16], my_hash[:16])
             roof["achieved"] = rays_per_launch_rank0 * lane_ops_per_ray / (kms * 1e-3) / 1e9
             roof["achieved_source"] = ("%s: useful VALU lane-ops per ray = %.1f (SQ_THREAD_CYCLES_VALU / rays, rocprofv3 --pmc pass of kernel %s, "
                                        "IMPORTED from %s) x %.4g rays per launch / %.2f ms render-kernel time, both measured in this run"
@@ -464,21 +788,20 @@ def main():
                                "never reach HBM: the inner tree is LDS resident and the rest is L2 resident (measured HBM traffic: roofline.traffic) -- "
                                "HBM is not the roof of this kernel, the vector issue port is"}
         t_d2h = time.perf_counter()
-        fb = r.read_fb()                       # outside the timed region: image checksum, identical for every N
+        checksum = checksum_of(job.root)       # outside the timed region: image checksum, identical for every N
         d2h_ms = (time.perf_counter() - t_d2h) * 1e3
-        checksum = int(sum(int(p.astype("int64").sum()) for p in fb))
         out = {
-            "metric": "Mray/s", "value": mray, "unit": "Mray/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "metric": "Mray/s", "value": mray, "unit": "Mray/s", "n_gpus": job.world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s (%d tris, %d BVH nodes), %dx%d, %d spp, depth %d" %
                                    (SCENE_NAMES.get(args.scene, "scene %d" % args.scene), scene.n_tris, scene.n_nodes, W, H, args.spp, args.depth),
                        "scene_id": args.scene,
-                       "bvh": "SAH (exact sweep below 8192 triangles, 256 bins above), one triangle per leaf, children ordered by distance to the scene's default camera" if args.bvh == 1 else "reference builder (bvh/bvh.cu:206-346)",
-                       "nan_direction_rays": "%.2f %% of the counted rays have a NaN direction (Sellmeier quirk Q1) and are answered 'miss' without walking the tree" % (100.0 * nan_c / rays_c),
-                       "tiles": "8x8 px per wave, rank = tile % n_gpus", "gather": gather_via},
+                       "bvh": BVH_NAMES.get(args.bvh, str(args.bvh)),
+                       "nan_direction_rays": "%.2f %% of the counted rays have a NaN direction (Sellmeier quirk Q1) and are answered 'miss' without walking the tree" % (100.0 * tc["nan_share"]),
+                       "tiles": "8x8 px per wave, rank = tile % n_gpus", "gather": job.gather_via, "launch_mode": job.launch_mode},
             "mpath_per_s": (W * H * args.spp * steps) / elapsed / 1e6,
-            "rays_per_path": rays_per_path, "node_records_per_ray_V": V, "tri_tests_per_ray_T": T, "algorithmic_bytes_per_ray": b_ray,
+            "rays_per_path": tc["rays_per_path"], "node_records_per_ray_V": tc["V"], "tri_tests_per_ray_T": tc["T"], "algorithmic_bytes_per_ray": b_ray,
             "kernel_ms_per_step": kms, "fb_checksum": checksum,
             # SURVEY 8(d)'s wall clock includes the hand-over of the framebuffer to the host; `value` / `ms_per_step` end with the
             # image in HBM (the boundary returns device memory), this adds the synchronous D2H of the three quantised planes
@@ -486,23 +809,51 @@ def main():
             "mray_per_s_incl_d2h": total_rays / steps / (elapsed / steps + d2h_ms * 1e-3) / 1e6,
             "roofline": roof,
         }
-        if per_rank is not None:
-            out["per_rank"] = per_rank
-            out["gather_check"] = gather_check
-        if not args.no_cpu_baseline and world == 1:     # the CPU baseline is reported at N=1 only
+        if job.world > 1:
+            rows = tf["rows"]
+            out["per_rank"] = {"kernel_ms": [round(x[0], 3) for x in rows], "rays_per_frame": [int(x[1]) for x in rows],
+                               "exchange_ms_after_own_kernel": [round(x[2], 3) for x in rows] if "ncclGather" in job.gather_via else None}
+            out["gather_check"] = job.gather_check
+
+    # ---- the CPU baseline (N = 1 only), while the headline scene is still uploaded -------------------------------------------
+    if out is not None and not args.no_cpu_baseline and job.world == 1:
+        try:
+            out["cpu_baseline"] = cpu_baseline(srt, scene, cam, W, H, args.depth, args.bvh, gpu_renderer=job.root)
+        except Exception as e:   # noqa: BLE001 -- the checker is optional for the measurement itself
+            out["cpu_baseline"] = {"value": None, "unit": "Mray/s", "cores": usable_cores()[0], "kind": "port", "sample": "failed: %r" % (e,)}
+        try:
+            out["cpu_baseline"]["cfg1_single_thread"] = cfg1_single_thread(srt)
+        except Exception as e:   # noqa: BLE001
+            out["cpu_baseline"]["cfg1_single_thread"] = {"value": None, "sample": "failed: %r" % (e,)}
+
+    # ---- the other BASELINE configurations, one frame each, after the timed region (every rank takes part: collectives inside) ----
+    others, cfg5 = [], None
+    if job.world == 1 and not args.no_other_configs:
+        for sid, bvh, w, h, spp, depth, name in ((100, 1, 1280, 720, 256, 16, "cfg 2"), (1, 0, 1920, 1080, 2048, 16, "cfg 4"), (101, 1, 3840, 2160, 512, 16, "cfg 5's scene at 512 spp")):
             try:
-                out["cpu_baseline"] = cpu_baseline(srt, scene, cam, W, H, args.depth, args.bvh, gpu_renderer=r)
-            except Exception as e:   # noqa: BLE001 -- the checker is optional for the measurement itself
-                out["cpu_baseline"] = {"value": None, "unit": "Mray/s", "cores": usable_cores()[0], "kind": "port", "sample": "failed: %r" % (e,)}
-            try:
-                out["cpu_baseline"]["cfg1_single_thread"] = cfg1_single_thread(srt)
-            except Exception as e:   # noqa: BLE001
-                out["cpu_baseline"]["cfg1_single_thread"] = {"value": None, "sample": "failed: %r" % (e,)}
+                rec = secondary_workload(srt, job, sid, bvh, w, h, spp, depth)
+                rec["baseline_config"] = name
+            except Exception as e:      # noqa: BLE001
+                rec = {"baseline_config": name, "value": None, "error": repr(e)}
+            others.append(rec)
+    if args.cfg5_spp > 0:
+        cw, ch = [int(x) for x in args.cfg5_size.lower().split("x")]
+        try:
+            cfg5 = secondary_workload(srt, job, 101, 1, cw, ch, args.cfg5_spp, 16)
+            if cfg5 is not None:
+                cfg5["baseline_config"] = "cfg 5 (BASELINE: 3840x2160, 4096 spp, tiles across the GPUs of the node, one RCCL gather)"
+        except Exception as e:      # noqa: BLE001
+            log("cfg 5 sub-record failed: %r" % (e,))
+            cfg5 = {"value": None, "error": repr(e)}
+    if out is not None:
+        if others:
+            out["other_configs"] = others
+        if cfg5 is not None:
+            out["cfg5"] = cfg5
         print(json.dumps(out), flush=True)
 
-    if comm is not None:
-        comm.close()
-    if world > 1:
+    job.close()
+    if launcher:
         dist.barrier()
         dist.destroy_process_group()
 

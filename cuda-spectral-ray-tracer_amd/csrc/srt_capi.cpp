@@ -38,6 +38,7 @@ struct srt_ctx {
     uint32_t n_lanes = 0;
     uint32_t rank = 0, world = 1;
     uint32_t gather_planes = 3;          // planes of the exchange unit: 3 = the quantised framebuffer, 9 = + the parity planes
+    uint32_t fb_groups_valid = 3;        // plane groups of d_fb the last scatter wrote (or all three, zeroed, right after init_device_params)
     // last chunk
     uint32_t last_w = 0, last_h = 0, last_offx = 0, last_offy = 0;
     uint32_t tiles_x = 0, tiles_y = 0, n_tiles = 0, tiles_local = 0, tiles_padded = 0;
@@ -63,6 +64,13 @@ struct srt_ctx {
     uint64_t lanes_allocated = 0;                       // size of d_rng / d_fb in lanes
     float last_probe_ms = 0.f;
     bool count_traversal = false;
+    // which render kernel a production launch uses: 0 = auto (render_kernel_duo when the scene qualifies and the launch is
+    // throughput-bound: at least duo_min_tiles tiles per persistent wave), 1 = always render_kernel, 2 = render_kernel_duo whenever
+    // the scene qualifies (srt_set_kernel_variant; env SRT_KERNEL_VARIANT / SRT_DUO_MIN_TILES)
+    int kernel_variant = 0;
+    uint32_t duo_min_tiles = 0xffffffffu;      // (auto never picks the duo kernel until a measured threshold is set here)
+    uint32_t duo_w_swap = 320, duo_w_blocked = 70, duo_fill_d = 40, duo_fill_g = 24, duo_fill_e = 40;      // env SRT_DUO_W_SWAP, ..._W_BLOCKED, ..._FILL_D / _G / _E
+    int last_variant = 0;                 // what the last srt_render_chunk launched: 0 render_kernel, 1 render_kernel_duo
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
     uint64_t last_paths = 0;
@@ -162,6 +170,13 @@ int srt_create(int device, srt_ctx **out) {
     if (const char *ev = getenv("SRT_SCORE_FRINGE")) c->score_fringe = (uint32_t)std::max(1, atoi(ev));   // 0 would starve fringe lanes
     if (const char *ev = getenv("SRT_DEBUG_LANE_LIMIT")) c->debug_lane_limit = (uint32_t)std::max(0, atoi(ev));
     if (const char *ev = getenv("SRT_SPLIT_LOAD")) c->split_load_pct = (uint32_t)std::max(0, atoi(ev));
+    if (const char *ev = getenv("SRT_KERNEL_VARIANT")) c->kernel_variant = std::min(2, std::max(0, atoi(ev)));
+    if (const char *ev = getenv("SRT_DUO_MIN_TILES")) c->duo_min_tiles = (uint32_t)std::max(0, atoi(ev));
+    if (const char *ev = getenv("SRT_DUO_W_SWAP")) c->duo_w_swap = (uint32_t)std::max(1, atoi(ev));
+    if (const char *ev = getenv("SRT_DUO_W_BLOCKED")) c->duo_w_blocked = (uint32_t)std::max(1, atoi(ev));
+    if (const char *ev = getenv("SRT_DUO_FILL_D")) c->duo_fill_d = (uint32_t)std::max(1, atoi(ev));
+    if (const char *ev = getenv("SRT_DUO_FILL_G")) c->duo_fill_g = (uint32_t)std::max(1, atoi(ev));
+    if (const char *ev = getenv("SRT_DUO_FILL_E")) c->duo_fill_e = (uint32_t)std::max(1, atoi(ev));
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->n_cu = prop.multiProcessorCount;
@@ -251,6 +266,18 @@ int srt_launch_plan(const srt_ctx *c, int *waves_per_cu, int *n_cached, int *all
     return SRT_OK;
 }
 
+int srt_set_kernel_variant(srt_ctx *c, int variant) {
+    if (!c || variant < 0 || variant > 2) return fail(c, SRT_ERR_INVALID, "srt_set_kernel_variant: variant must be 0 (auto), 1 (render_kernel) or 2 (render_kernel_duo)");
+    c->kernel_variant = variant;
+    return SRT_OK;
+}
+
+int srt_last_kernel_variant(const srt_ctx *c, int *variant) {
+    if (!c || !variant) return fail(nullptr, SRT_ERR_INVALID, "srt_last_kernel_variant: null argument");
+    *variant = c->last_variant;
+    return SRT_OK;
+}
+
 int srt_launch_lds_bytes(const srt_ctx *c, size_t *bytes) {
     if (!c || !c->scene_ready || !bytes) return fail(nullptr, SRT_ERR_INVALID, "srt_launch_lds_bytes: no scene uploaded / null argument");
     LaunchPlan plan;
@@ -259,8 +286,10 @@ int srt_launch_lds_bytes(const srt_ctx *c, size_t *bytes) {
     return SRT_OK;
 }
 
-int srt_init_device_params(srt_ctx *c, uint32_t tx, uint32_t ty, uint32_t bx, uint32_t by, uint32_t chunk_w, uint32_t chunk_h,
-                           uint32_t spp, uint32_t bounce_limit, uint64_t seed) {
+// srt_init_device_params without the final device-wide wait: a communicator that drives several GPUs from one process enqueues
+// the re-seeding on all of them before it waits for any (srt_comm_init_device_params)
+int srt_internal_init_device_params(srt_ctx *c, uint32_t tx, uint32_t ty, uint32_t bx, uint32_t by, uint32_t chunk_w, uint32_t chunk_h,
+                                    uint32_t spp, uint32_t bounce_limit, uint64_t seed, int wait) {
     if (!c) return fail(c, SRT_ERR_INVALID, "srt_init_device_params: null ctx");
     if (tx == 0 || ty == 0 || bx == 0 || by == 0 || chunk_w == 0 || chunk_h == 0)
         return fail(c, SRT_ERR_INVALID, "srt_init_device_params: zero dimension");
@@ -280,9 +309,15 @@ int srt_init_device_params(srt_ctx *c, uint32_t tx, uint32_t ty, uint32_t bx, ui
     }
     HIP_TRY(c, hipMemset(c->d_fb, 0, kTilePlanes * lanes * sizeof(float)));
     HIP_TRY(c, launch_init_rng(c->d_rng, c->n_lanes, seed, nullptr));   // init_random_states, rendering.cu:330
-    HIP_TRY(c, hipDeviceSynchronize());
+    if (wait) HIP_TRY(c, hipDeviceSynchronize());
+    c->fb_groups_valid = (uint32_t)kTileGroups;      // all nine planes are zero
     c->params_ready = true;
     return SRT_OK;
+}
+
+int srt_init_device_params(srt_ctx *c, uint32_t tx, uint32_t ty, uint32_t bx, uint32_t by, uint32_t chunk_w, uint32_t chunk_h,
+                           uint32_t spp, uint32_t bounce_limit, uint64_t seed) {
+    return srt_internal_init_device_params(c, tx, ty, bx, by, chunk_w, chunk_h, spp, bounce_limit, seed, 1);
 }
 
 int srt_set_partition(srt_ctx *c, uint32_t rank, uint32_t world) {
@@ -346,6 +381,15 @@ int srt_render_chunk(srt_ctx *c, uint32_t width, uint32_t height, uint32_t offx,
     p.tile_order = nullptr; p.tile_cost = nullptr; p.queue_rows = nullptr; p.queue_rows_bound = c->tiles_local;
     p.debug_lane_limit = c->debug_lane_limit;
     const bool ordered = c->probe_spp > 0 && c->spp > 4 * c->probe_spp && c->tiles_local > 1 && c->tiles_local <= 0x3fffffu;   // 22-bit tile field of a queue row
+    // The two-context kernel (srt_kernels_duo.hip) for launches that are throughput-bound: a pixel's chain advances at half speed
+    // when it shares its lane, so it needs many tiles per persistent wave; its queue rows are whole tiles (never split).
+    bool use_duo = false;
+    if (!c->count_traversal && c->kernel_variant != 1 && render_duo_eligible(c->stack_depth, c->n_records, c->n_inner, c->root_ref)) {
+        const uint64_t duo_waves = (uint64_t)c->n_cu * kDuoWavesPerBlock;
+        use_duo = c->kernel_variant == 2 || (uint64_t)c->tiles_local >= (uint64_t)c->duo_min_tiles * duo_waves;
+    }
+    p.duo_w_swap = c->duo_w_swap; p.duo_w_blocked = c->duo_w_blocked;
+    p.duo_fill_d = c->duo_fill_d; p.duo_fill_g = c->duo_fill_g; p.duo_fill_e = c->duo_fill_e;
     if (ordered) {
         if (c->tiles_local > c->tile_sched_capacity) {
             if (c->d_tile_cost) { (void)hipFree(c->d_tile_cost); c->d_tile_cost = nullptr; }
@@ -361,12 +405,13 @@ int srt_render_chunk(srt_ctx *c, uint32_t width, uint32_t height, uint32_t offx,
         pp.spp = c->probe_spp; pp.tile_cost = c->d_tile_cost;
         RoctxRange range_probe("srt cost probe + pixel queue");
         HIP_TRY(c, launch_render(pp, (uint32_t)c->n_cu, 2, st));
-        HIP_TRY(c, launch_order_tiles(c->d_tile_cost, sorted, rows, c->tiles_local, (uint32_t)c->n_cu * (uint32_t)plan.waves_per_cu, c->split_load_pct, queue_info, st));   // device-side, no host sync
+        const uint32_t split_pct = use_duo ? 0u : c->split_load_pct;
+        HIP_TRY(c, launch_order_tiles(c->d_tile_cost, sorted, rows, c->tiles_local, (uint32_t)c->n_cu * (uint32_t)plan.waves_per_cu, split_pct, queue_info, st));   // device-side, no host sync
         HIP_TRY(c, hipMemsetAsync(c->d_counters + kCounters, 0, sizeof(unsigned long long), st));   // rewind the queue head
         p.tile_order = rows;
         p.queue_rows = queue_info;
         p.prio_cost = c->d_tile_cost;      // wave priorities of the render launch (render_kernel, LDS-resident trees)
-        if (c->split_load_pct) p.queue_rows_bound = (uint32_t)std::min<uint64_t>((uint64_t)c->tiles_local * 64, 0x7fffffffull);
+        if (split_pct) p.queue_rows_bound = (uint32_t)std::min<uint64_t>((uint64_t)c->tiles_local * 64, 0x7fffffffull);
     }
     if (c->count_traversal) {
         const uint32_t n_waves = (uint32_t)c->n_cu * (uint32_t)plan.waves_per_cu;
@@ -380,7 +425,9 @@ int srt_render_chunk(srt_ctx *c, uint32_t width, uint32_t height, uint32_t offx,
     }
     RoctxRange range_render("srt render_kernel");
     HIP_TRY(c, hipEventRecord(c->ev0, st));     // ev0..ev1 bracket the render kernel alone (roofline.achieved)
-    HIP_TRY(c, launch_render(p, (uint32_t)c->n_cu, c->count_traversal ? 1 : 0, st));
+    if (use_duo) HIP_TRY(c, launch_render_duo(p, (uint32_t)c->n_cu, st));
+    else HIP_TRY(c, launch_render(p, (uint32_t)c->n_cu, c->count_traversal ? 1 : 0, st));
+    c->last_variant = use_duo ? 1 : 0;
     HIP_TRY(c, hipEventRecord(c->ev1, st));
     c->timed = true;
     c->last_paths = 0;   // filled by srt_get_stats from the tile ownership
@@ -428,6 +475,7 @@ int srt_scatter_tiles(srt_ctx *c, const void *dev_gathered, void *stream) {
     sp.tx = c->tx; sp.ty = c->ty; sp.bx = c->bx; sp.by = c->by;
     sp.tiles_x = c->tiles_x; sp.n_tiles = c->n_tiles; sp.world = c->world; sp.tiles_padded = c->tiles_padded;
     HIP_TRY(c, launch_scatter(sp, (hipStream_t)stream));
+    c->fb_groups_valid = groups;      // with a 3-plane exchange unit the parity planes of d_fb are NOT those of this frame
     return SRT_OK;
 }
 
@@ -454,6 +502,9 @@ int srt_read_fb(srt_ctx *c, float *r, float *g, float *b) { return read_planes(c
 
 int srt_read_fb_aux(srt_ctx *c, int which, float *p0, float *p1, float *p2) {
     if (which != 1 && which != 2) return fail(c, SRT_ERR_INVALID, "srt_read_fb_aux: which must be 1 (sRGB) or 2 (XYZ)");
+    if (c && (uint32_t)which >= c->fb_groups_valid)
+        return fail(c, SRT_ERR_UNSUPPORTED, "srt_read_fb_aux: the parity planes of the last frame were not gathered (the exchange unit was the 3 quantised "
+                                            "planes; srt_set_gather_planes / srt_comm_set_gather_planes(.., 9) before rendering moves all nine)");
     return read_planes(c, 3 * which, p0, p1, p2);
 }
 

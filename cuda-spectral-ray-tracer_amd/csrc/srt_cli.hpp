@@ -3,7 +3,7 @@
 // _log_/log_context.{h,cpp} (`log_context`), utils/utility.h:32-41 (`string_to_filename`).
 //
 // Header-only and free of GPU / library calls, so that the CPU suite can hold it against the reference's own params.cpp /
-// log_context.cpp compiled from their sources (oracle/Makefile target `ref`, tests/test_ref_host.py).
+// log_context.cpp compiled from their sources (tests/test_ref_host.py).
 #pragma once
 #include <algorithm>
 #include <chrono>

@@ -37,6 +37,8 @@ struct RcclApi {
     decltype(&ncclCommInitAll) CommInitAll = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
     decltype(&ncclGather) Gather = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    bool test_transport = false;       // the loaded library exports srt_mock_rccl_marker: tests/cpp/mock_rccl.cpp, not RCCL
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
@@ -65,11 +67,13 @@ RcclApi &rccl() {
             cand.CommInitAll = (decltype(cand.CommInitAll))sym("ncclCommInitAll");
             cand.CommDestroy = (decltype(cand.CommDestroy))sym("ncclCommDestroy");
             cand.Gather = (decltype(cand.Gather))sym("ncclGather");
+            cand.AllGather = (decltype(cand.AllGather))sym("ncclAllGather");
             cand.GroupStart = (decltype(cand.GroupStart))sym("ncclGroupStart");
             cand.GroupEnd = (decltype(cand.GroupEnd))sym("ncclGroupEnd");
             cand.GetErrorString = (decltype(cand.GetErrorString))sym("ncclGetErrorString");
             if (!ok) { dlclose(h); return; }
             cand.handle = h; cand.preloaded = preloaded;
+            cand.test_transport = dlsym(h, "srt_mock_rccl_marker") != nullptr;
             api = cand;
         };
         auto try_open = [&](const char *n, int flags, bool preloaded) {
@@ -103,6 +107,11 @@ struct srt_comm {
     float *d_gathered = nullptr;       // on rank 0's device: world * tiles_padded * 9 * 64 floats, rank-major
     size_t gathered_capacity = 0;
     uint32_t gather_planes = 3;        // 3: the quantised framebuffer only (12 B / pixel); 9: + the parity planes
+    // one process per GPU only: the ranks set their plane count independently, and ncclGather with different counts hangs or
+    // corrupts.  The first frame after the count (or the communicator) changed exchanges the counts (one 4-byte all-gather) and
+    // every rank fails with the same message when they differ.
+    bool planes_agreed = false;
+    uint32_t *d_agree = nullptr;       // world words on this rank's device
     std::vector<hipEvent_t> ev_g0, ev_g1;   // per local context: around the gather (+ scatter on rank 0) of the last frame
     bool gather_timed = false;
     std::string err;
@@ -154,6 +163,7 @@ int srt_comm_available(void) {
 int srt_comm_set_gather_planes(srt_comm *c, uint32_t planes) {
     if (!c || (planes != 3 && planes != 9)) return cfail(c, SRT_ERR_INVALID, "srt_comm_set_gather_planes: planes must be 3 or 9");
     for (srt_ctx *x : c->ctx) { int rc = srt_set_gather_planes(x, planes); if (rc != SRT_OK) return cfail(c, rc, srt_last_error(x)); }
+    if (planes != c->gather_planes && !c->owns_ctx) c->planes_agreed = false;      // (srt_comm_init_all: this call sets every rank's count)
     c->gather_planes = planes;
     return SRT_OK;
 }
@@ -184,16 +194,19 @@ int srt_comm_init_rank(srt_ctx *ctx, const unsigned char id[SRT_COMM_ID_BYTES], 
 int srt_comm_init_all(const int *devices, int n, srt_comm **out) {
     if (!devices || n <= 0 || !out) return cfail(nullptr, SRT_ERR_INVALID, "srt_comm_init_all: bad argument");
     *out = nullptr;
-    // (SRT_COMM_TEST_SAME_DEVICE=1: test hook -- several ranks on one GPU, only meaningful with a transport that allows it:
-    // tests/cpp/mock_rccl.cpp through SRT_RCCL_LIB; RCCL itself refuses a device that appears twice)
-    const char *same = getenv("SRT_COMM_TEST_SAME_DEVICE");
-    for (int i = 0; i < n && !(same && same[0] == '1'); i++)
-        for (int j = 0; j < i; j++)
-            if (devices[i] == devices[j]) return cfail(nullptr, SRT_ERR_INVALID, "srt_comm_init_all: a device is listed twice (one rank per GPU)");
     RcclApi &R = rccl();
     if (!R.handle) return cfail(nullptr, SRT_ERR_UNSUPPORTED, "srt_comm_init_all: " + R.error);
+    // One rank per GPU.  Test hook: SRT_COMM_TEST_SAME_DEVICE=1 lets several ranks share a device, and is honoured ONLY when the
+    // loaded transport identifies itself as the test transport (tests/cpp/mock_rccl.cpp exports srt_mock_rccl_marker; loaded
+    // through SRT_RCCL_LIB) -- a duplicate device never reaches the real ncclCommInitAll.
+    const char *same = getenv("SRT_COMM_TEST_SAME_DEVICE");
+    const bool allow_same = same && same[0] == '1' && R.test_transport;
+    for (int i = 0; i < n && !allow_same; i++)
+        for (int j = 0; j < i; j++)
+            if (devices[i] == devices[j]) return cfail(nullptr, SRT_ERR_INVALID, "srt_comm_init_all: a device is listed twice (one rank per GPU)");
     srt_comm *c = new srt_comm();
     c->world = (uint32_t)n; c->owns_ctx = true; c->root_local = 0;
+    c->planes_agreed = true;           // one process sets the count of every rank (srt_comm_set_gather_planes): agreed by construction
     c->ctx.assign(n, nullptr); c->rank.resize(n); c->nccl.assign(n, nullptr); c->stream.assign(n, nullptr);
     c->ev_g0.assign(n, nullptr); c->ev_g1.assign(n, nullptr);
     for (int i = 0; i < n; i++) {
@@ -222,6 +235,7 @@ void srt_comm_destroy(srt_comm *c) {
         if (i < c->ev_g1.size() && c->ev_g1[i]) (void)hipEventDestroy(c->ev_g1[i]);
     }
     if (c->d_gathered && c->root_local >= 0) { (void)hipSetDevice(device_of(c->ctx[c->root_local])); (void)hipFree(c->d_gathered); }
+    if (c->d_agree && !c->ctx.empty() && c->ctx[0]) { (void)hipSetDevice(device_of(c->ctx[0])); (void)hipFree(c->d_agree); }
     if (c->owns_ctx) for (srt_ctx *x : c->ctx) if (x) srt_destroy(x);
     delete c;
 }
@@ -245,10 +259,16 @@ int srt_comm_set_camera(srt_comm *c, const srt_camera_data *cam) {
 int srt_comm_init_device_params(srt_comm *c, uint32_t tx, uint32_t ty, uint32_t bx, uint32_t by, uint32_t chunk_w, uint32_t chunk_h,
                                 uint32_t spp, uint32_t bounce_limit, uint64_t seed) {
     if (!c) return cfail(c, SRT_ERR_INVALID, "srt_comm_init_device_params: null comm");
+    // enqueue the re-seeding on every local device first, then wait for all of them: N devices take the time of one
     for (srt_ctx *x : c->ctx) {
-        int rc = srt_init_device_params(x, tx, ty, bx, by, chunk_w, chunk_h, spp, bounce_limit, seed);
+        int rc = srt_internal_init_device_params(x, tx, ty, bx, by, chunk_w, chunk_h, spp, bounce_limit, seed, c->ctx.size() == 1 ? 1 : 0);
         if (rc != SRT_OK) return cfail(c, rc, srt_last_error(x));
     }
+    if (c->ctx.size() > 1)
+        for (srt_ctx *x : c->ctx) {
+            COMM_HIP(c, hipSetDevice(device_of(x)));
+            COMM_HIP(c, hipDeviceSynchronize());
+        }
     return SRT_OK;
 }
 
@@ -270,6 +290,23 @@ int srt_render_frame_multi(srt_comm *c, uint32_t width, uint32_t height, uint32_
     if (c->world == 1) {
         rc = srt_scatter_tiles(c->ctx[0], nullptr, c->stream[0]);
         return rc == SRT_OK ? SRT_OK : cfail(c, rc, srt_last_error(c->ctx[0]));
+    }
+    if (!c->planes_agreed) {
+        // (process-per-GPU communicators only, once per change of the plane count: see srt_comm::planes_agreed)
+        COMM_HIP(c, hipSetDevice(device_of(c->ctx[0])));
+        if (!c->d_agree) COMM_HIP(c, hipMalloc((void **)&c->d_agree, (size_t)(c->world + 1) * sizeof(uint32_t)));
+        const uint32_t mine = c->gather_planes;
+        COMM_HIP(c, hipMemcpyAsync(c->d_agree + c->world, &mine, sizeof(mine), hipMemcpyHostToDevice, c->stream[0]));
+        COMM_NCCL(c, R.AllGather(c->d_agree + c->world, c->d_agree, 1, ncclUint32, c->nccl[0], c->stream[0]));
+        std::vector<uint32_t> all(c->world);
+        COMM_HIP(c, hipMemcpyAsync(all.data(), c->d_agree, c->world * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream[0]));
+        COMM_HIP(c, hipStreamSynchronize(c->stream[0]));
+        for (uint32_t r = 0; r < c->world; r++)
+            if (all[r] != mine)
+                return cfail(c, SRT_ERR_INVALID, "srt_render_frame_multi: the ranks disagree on the exchange unit (rank " + std::to_string(r) + " gathers " +
+                                                     std::to_string(all[r]) + " planes, this rank " + std::to_string(mine) +
+                                                     "): call srt_comm_set_gather_planes with the same value on every rank");
+        c->planes_agreed = true;
     }
     if (c->root_local >= 0 && (size_t)c->world * n_floats > c->gathered_capacity) {
         COMM_HIP(c, hipSetDevice(device_of(c->ctx[c->root_local])));

@@ -191,6 +191,13 @@ SRT_API int srt_set_camera(srt_ctx *ctx, const srt_camera_data *cam);
  * records resident in LDS, whether that is the whole inner tree (kernel variant ALL_CACHED) and whether record references fit 15
  * bits (variant NARROW).  Any pointer may be NULL. */
 SRT_API int srt_launch_plan(const srt_ctx *ctx, int *waves_per_cu, int *n_cached, int *all_cached, int *narrow_refs);
+/* Two render kernels produce the same image: render_kernel (one pixel per lane: the shortest chain per pixel) and render_kernel_duo
+ * (two pixels per lane, shading batched by material class: more rays per second when a launch has many tiles per wave).  variant
+ * 0 (default) chooses per launch, 1 = always render_kernel, 2 = render_kernel_duo whenever the scene qualifies (inner tree LDS
+ * resident, 15-bit record references).  Instrumented launches (srt_set_count_traversal) always use render_kernel.
+ * srt_last_kernel_variant: what the last srt_render_chunk launched (0 render_kernel, 1 render_kernel_duo). */
+SRT_API int srt_set_kernel_variant(srt_ctx *ctx, int variant);
+SRT_API int srt_last_kernel_variant(const srt_ctx *ctx, int *variant);
 /* Dynamic LDS bytes of one workgroup of that launch (tables + inner-record cache + traversal stacks): the counterpart of the
  * reference's shared_mem_size (rendering/rendering.cu:290-301), which its run log reports as "shared memory byte size" (:342). */
 SRT_API int srt_launch_lds_bytes(const srt_ctx *ctx, size_t *bytes);
@@ -233,7 +240,8 @@ SRT_API int srt_read_fb(srt_ctx *ctx, float *r, float *g, float *b);
 /* D2H + the un-swizzle of render_manager::update_fb (render_manager.cuh:68-142) done on the device:
  * writes the last rendered chunk into row-major image planes of width image_width at (offx, offy). */
 SRT_API int srt_read_fb_rowmajor(srt_ctx *ctx, float *r, float *g, float *b, uint32_t image_width, uint32_t image_height);
-/* Parity planes, block-linear: which = 1 unquantised sRGB in [0,1] (value before expand_sRGB), 2 = XYZ sums. */
+/* Parity planes, block-linear: which = 1 unquantised sRGB in [0,1] (value before expand_sRGB), 2 = XYZ sums.  SRT_ERR_UNSUPPORTED
+ * when the last scatter did not write them (multi-GPU frame with the default 3-plane exchange unit). */
 SRT_API int srt_read_fb_aux(srt_ctx *ctx, int which, float *p0, float *p1, float *p2);
 
 /* Scheduling introspection: per-local-tile traversal cost measured by the probe of the last ordered launch (n = tiles_local). */
@@ -275,7 +283,11 @@ SRT_API int srt_comm_init_rank(srt_ctx *ctx, const unsigned char id[SRT_COMM_ID_
  * launcher lets every rank call it and agrees on the exchange path BEFORE any rank enters the collective srt_comm_init_rank.
  * An RCCL the host process already mapped (PyTorch's) is re-used; SRT_RCCL_LIB names an explicit library. */
 SRT_API int srt_comm_available(void);
-/* Planes the gather moves: 3 (default) = the quantised framebuffer, 12 B / pixel; 9 = + the parity planes (72 B / pixel). */
+/* Planes the gather moves: 3 (default) = the quantised framebuffer, 12 B / pixel; 9 = + the parity planes (72 B / pixel).
+ * With one process per GPU EVERY rank must set the same value: the first srt_render_frame_multi after a change exchanges the
+ * counts (one 4-byte all-gather) and fails with SRT_ERR_INVALID on every rank when they differ, instead of entering ncclGather
+ * with mismatched counts.  After a 3-plane frame rank 0's parity planes are not this frame's: srt_read_fb_aux returns
+ * SRT_ERR_UNSUPPORTED until a 9-plane frame (or a single-GPU scatter) has written them. */
 SRT_API int srt_comm_set_gather_planes(srt_comm *comm, uint32_t planes);
 SRT_API void srt_comm_destroy(srt_comm *comm);                 /* destroys the contexts srt_comm_init_all created */
 SRT_API const char *srt_comm_last_error(const srt_comm *comm);

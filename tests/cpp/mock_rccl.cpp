@@ -1,4 +1,4 @@
-// mock_rccl.cpp -- TEST TRANSPORT, not RCCL: the eight entry points csrc/srt_comm.cpp resolves, implemented with HIP copies inside ONE
+// mock_rccl.cpp -- TEST TRANSPORT, not RCCL: the nine entry points csrc/srt_comm.cpp resolves, implemented with HIP copies inside ONE
 // process, so that the W > 1 branch of srt_render_frame_multi (gathered-buffer allocation, the grouped gather calls, the scatter from
 // the rank-major buffer, the exchange timing) runs on a box with a single GPU.  Loaded through SRT_RCCL_LIB by
 // tests/test_gpu_parity.py::test_comm_two_ranks_one_gpu_mock_transport; never by the product.
@@ -33,6 +33,17 @@ static ncclResult_t flush() {
 }
 
 extern "C" {
+// identifies this library as the test transport: csrc/srt_comm.cpp honours SRT_COMM_TEST_SAME_DEVICE only when it finds this symbol
+__attribute__((visibility("default"))) int srt_mock_rccl_marker = 1;
+// all-gather of `count` elements per rank, used by the library once per communicator to agree on the exchange unit; in this
+// single-process transport every rank of a communicator formed by ncclCommInitRank is alone in its process (world 1 in the tests)
+// or shares the process (ncclCommInitAll: the library never calls it there): copy own contribution to every slot it owns
+__attribute__((visibility("default"))) ncclResult_t ncclAllGather(const void *send, void *recv, size_t count, ncclDataType_t type, ncclComm_t comm, hipStream_t stream) {
+    if (!comm || (type != ncclUint32 && type != ncclFloat && type != ncclInt32)) return ncclInvalidArgument;
+    MockComm *m = (MockComm *)comm;
+    if (m->world != 1) return ncclInvalidUsage;      // (would need a rendezvous between ranks: not what this mock is for)
+    return hipMemcpyAsync(recv, send, count * 4, hipMemcpyDeviceToDevice, stream) == hipSuccess ? ncclSuccess : ncclUnhandledCudaError;
+}
 __attribute__((visibility("default"))) ncclResult_t ncclGetUniqueId(ncclUniqueId *id) { memset(id, 7, sizeof(*id)); return ncclSuccess; }
 __attribute__((visibility("default"))) ncclResult_t ncclCommInitRank(ncclComm_t *comm, int world, ncclUniqueId, int rank) {
     *comm = (ncclComm_t) new MockComm{rank, world};

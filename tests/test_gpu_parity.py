@@ -565,7 +565,8 @@ def test_comm_two_and_three_ranks_one_gpu_mock_transport():
     """The W > 1 branch of srt_render_frame_multi -- gathered-buffer allocation, the grouped gather calls, the scatter from the
     rank-major buffer (3-plane exchange unit and 9-plane parity unit), exchange timing, per-comm statistics -- on ONE GPU: two / three
     ranks on device 0 (test hook SRT_COMM_TEST_SAME_DEVICE) over a test transport that implements the eight RCCL entry points with
-    HIP copies (tests/cpp/mock_rccl.cpp, loaded through SRT_RCCL_LIB).  Everything but RCCL itself.  The library caches its RCCL
+    HIP copies (tests/cpp/mock_rccl.cpp, loaded through SRT_RCCL_LIB; the hook is honoured only for a transport that exports the
+    mock's marker symbol).  Everything but RCCL itself.  The library caches its RCCL
     handle per process, so this runs in a child process."""
     import subprocess
     import sys
@@ -596,6 +597,13 @@ for world in (2, 3):
         if planes == 9:
             assert_planes_equal(root.read_fb_aux(2), ref['xyz'], 'world %%d xyz' %% world)
             assert_planes_equal(root.read_fb_aux(1), ref['lin'], 'world %%d lin' %% world)
+        else:
+            # the parity planes did not travel: asking for them is an error, not stale data (ADVICE r3)
+            try:
+                root.read_fb_aux(2)
+                raise AssertionError('read_fb_aux after a 3-plane gather must fail')
+            except srt.SrtError as e:
+                assert e.code == -5 and 'not gathered' in str(e), e
         st = comm.stats()
         assert st['rays'] == ref['stats']['rays'] and st['paths'] == ref['stats']['paths'], (st, ref['stats'])
         assert comm.last_gather_ms() > 0.0
@@ -605,6 +613,45 @@ print('mock transport ok')
     env = dict(os.environ, SRT_RCCL_LIB=mock, SRT_COMM_TEST_SAME_DEVICE="1")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "mock transport ok" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])
+
+
+def test_bench_single_process_two_ranks_mock_transport():
+    """`python bench.py --gpus 2` WITHOUT a launcher -- the shape of the driver's N = 1 command: one process drives the ranks through
+    srt_comm_init_all / srt_render_frame_multi -- rehearsed at W = 2 on ONE GPU over the test transport: it must print a line
+    (round 3 exited with "must be launched with torch.distributed.run"), the line must say which launch mode ran, carry per_rank
+    rows, a passed gather_check, the cfg 5 sub-record, and the same framebuffer checksums as the one-GPU run of the same workload."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    mock = os.path.join(root, "tests", "cpp", "_build", "libmock_rccl.so")
+    if not os.path.exists(mock):
+        pytest.skip("tests/cpp/_build/libmock_rccl.so not built (__graft_entry__.build())")
+    common = ["--width", "200", "--height", "120", "--spp", "24", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-calibration",
+              "--no-other-configs", "--cfg5-spp", "12", "--cfg5-size", "160x90"]
+
+    def run(gpus, env):
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(gpus)] + common, env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+        lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, out.stdout[-1500:]
+        return json.loads(lines[0])
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    one = run(1, env)
+    two = run(2, dict(env, SRT_RCCL_LIB=mock, SRT_COMM_TEST_SAME_DEVICE="1"))
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2
+    assert "one process drives all GPUs" in two["config"]["launch_mode"] and "srt_comm_init_all" in two["config"]["launch_mode"]
+    assert "ncclGather inside libsrt_hip.so" in two["config"]["gather"], two["config"]["gather"]
+    assert two["gather_check"].startswith("verified"), two["gather_check"]
+    assert len(two["per_rank"]["kernel_ms"]) == 2 and all(x > 0 for x in two["per_rank"]["kernel_ms"])
+    assert sum(two["per_rank"]["rays_per_frame"]) * two["steps"] == round(two["value"] * 1e6 * two["ms_per_step"] * 1e-3 * two["steps"])
+    assert two["fb_checksum"] == one["fb_checksum"] and two["fb_checksum"] > 0
+    assert sum(two["per_rank"]["rays_per_frame"]) == round(one["value"] * 1e6 * one["ms_per_step"] * 1e-3)          # the same rays, split
+    for line in (one, two):
+        assert line["cfg5"]["value"] > 0 and "100k-triangle mesh" in line["cfg5"]["workload"] and "160x90, 12 spp" in line["cfg5"]["workload"]
+    assert two["cfg5"]["fb_checksum"] == one["cfg5"]["fb_checksum"] and two["cfg5"]["rays"] == one["cfg5"]["rays"]
+    assert len(two["cfg5"]["per_rank_kernel_ms"]) == 2
+    assert "nan_direction_rays" in two["config"]
 
 
 def _custom_scene(srt, tris, mats, bg_rgb=(0.5, 0.5, 0.5)):

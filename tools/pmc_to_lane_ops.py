@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Turns a tools/pmc_passes.sh result (summary.txt + one of its pass*.json bench lines) into the entry of
-profiles/r03/lane_ops_per_ray.json that bench.py imports for roofline.achieved.  The entry carries the hash of the kernel's ISA
+profiles/r04/lane_ops_per_ray.json that bench.py imports for roofline.achieved.  The entry carries the hash of the kernel's ISA
 listing (tools/kernel_id.py) taken from the pass's own bench line, so bench.py can tell a figure that belongs to another binary.
 
 usage: tools/pmc_to_lane_ops.py <pmc dir> <kernel tag> [scene id] [output json]
@@ -26,7 +26,7 @@ w, h, spp = [int(x) for x in re.search(r"(\d+)x(\d+), (\d+) spp", b["config"]["w
 rays = w * h * spp * b["rays_per_path"]
 wc = c["SQ_WAVE_CYCLES"]
 entry = {
-    "kernel": tag, "kernel_isa_sha256": (b.get("roofline") or {}).get("kernel_isa_sha256"), "kernel_variant": (b.get("roofline") or {}).get("kernel"), "source": "tools/pmc_passes.sh: rocprofv3 --pmc <set> --kernel-trace, one counter set per run, render_kernel<0,...> dispatch, %dx%d, %d spp" % (w, h, spp),
+    "kernel": tag, "kernel_code_sha256": (b.get("roofline") or {}).get("kernel_code_sha256"), "kernel_isa_sha256": (b.get("roofline") or {}).get("kernel_isa_sha256"), "kernel_variant": (b.get("roofline") or {}).get("kernel"), "source": "tools/pmc_passes.sh: rocprofv3 --pmc <set> --kernel-trace, one counter set per run, render_kernel<0,...> dispatch, %dx%d, %d spp" % (w, h, spp),
     "rays_in_pmc_launch": rays,
     "lane_ops_per_ray": c["SQ_THREAD_CYCLES_VALU"] / rays,
     "valu_wave_instr_per_ray": c["SQ_INSTS_VALU"] / rays, "salu_wave_instr_per_ray": c["SQ_INSTS_SALU"] / rays,
@@ -40,7 +40,7 @@ entry = {
     "hbm_note": "FETCH_SIZE + WRITE_SIZE (KiB) of the dispatch, raw; the gfx950 2x correction of MI355X_MICROARCH.md applies to wide coalesced streams, these are lone 4-byte RNG / result accesses (uncalibrated pattern), so the raw value is kept",
     "counters": c,
 }
-out = sys.argv[4] if len(sys.argv) > 4 else os.path.join(ROOT, "profiles", "r03", "lane_ops_per_ray.json")
+out = sys.argv[4] if len(sys.argv) > 4 else os.path.join(ROOT, "profiles", "r04", "lane_ops_per_ray.json")
 os.makedirs(os.path.dirname(out), exist_ok=True)
 doc = json.load(open(out)) if os.path.exists(out) else {}
 doc["scene_%d" % scene] = entry

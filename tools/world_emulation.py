@@ -10,6 +10,7 @@ ap.add_argument("--scene", type=int, default=100); ap.add_argument("--bvh", type
 ap.add_argument("--width", type=int, default=1920); ap.add_argument("--height", type=int, default=1080)
 ap.add_argument("--spp", type=int, default=1024); ap.add_argument("--depth", type=int, default=16)
 ap.add_argument("--worlds", default="1,2,4,8"); ap.add_argument("--reps", type=int, default=1)
+ap.add_argument("--ranks", default="", help="only these ranks of every world (default: all)")
 a = ap.parse_args()
 scene = srt.Scene.builtin(a.scene, 0).build_bvh(a.bvh, 1984)
 cam = scene.default_camera(a.width, a.height)
@@ -19,7 +20,7 @@ r.set_partition(0, 1); r.init_device_params(a.width, a.height, 8, a.depth, 1984)
 out = {}
 for W in [int(x) for x in a.worlds.split(",")]:
     ms = []
-    for rank in range(W):
+    for rank in ([int(x) for x in a.ranks.split(',') if int(x) < W] if a.ranks else range(W)):
         r.set_partition(rank, W)
         best = 1e30
         for _ in range(a.reps):
