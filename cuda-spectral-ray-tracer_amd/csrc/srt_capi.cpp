@@ -59,6 +59,8 @@ struct srt_ctx {
     uint32_t debug_lane_limit = 0;                     // env SRT_DEBUG_LANE_LIMIT (experiments: partial tiles)
     uint32_t split_load_pct = 200;                    // env SRT_SPLIT_LOAD: load factor (%) of the capacity constraint in order_tiles_kernel's split policy (0 = never split)
     uint32_t probe_spp = 2;                            // samples of the cost probe (env SRT_PROBE_SPP, 0 = no ordering)
+    uint32_t split_by_key = 0;                         // split policy: latency from the sort key instead of the tile cost (env SRT_SPLIT_BY_KEY)
+    uint32_t order_max_pct = 0;                        // queue order: tile cost moved this % towards 64 x its most expensive pixel (env SRT_ORDER_MAX_PCT)
     uint32_t *d_tile_cost = nullptr, *d_tile_order = nullptr;
     size_t tile_sched_capacity = 0;
     uint64_t lanes_allocated = 0;                       // size of d_rng / d_fb in lanes
@@ -145,6 +147,7 @@ void fill_params(const srt_ctx *c, RenderParams &p) {
     p.rng = c->d_rng; p.n_lanes = c->n_lanes;
     p.tile_out = c->d_tiles; p.counters = c->d_counters;
     p.tile_group_stride = c->tiles_padded * (uint32_t)(kGroupPlanes * kTileLanes);
+    p.write_parity = c->gather_planes == (uint32_t)kTilePlanes ? 1u : 0u;
 }
 
 }  // namespace
@@ -170,6 +173,8 @@ int srt_create(int device, srt_ctx **out) {
     if (const char *ev = getenv("SRT_SCORE_FRINGE")) c->score_fringe = (uint32_t)std::max(1, atoi(ev));   // 0 would starve fringe lanes
     if (const char *ev = getenv("SRT_DEBUG_LANE_LIMIT")) c->debug_lane_limit = (uint32_t)std::max(0, atoi(ev));
     if (const char *ev = getenv("SRT_SPLIT_LOAD")) c->split_load_pct = (uint32_t)std::max(0, atoi(ev));
+    if (const char *ev = getenv("SRT_SPLIT_BY_KEY")) c->split_by_key = atoi(ev) ? 1u : 0u;
+    if (const char *ev = getenv("SRT_ORDER_MAX_PCT")) c->order_max_pct = (uint32_t)std::min(400, std::max(0, atoi(ev)));
     if (const char *ev = getenv("SRT_KERNEL_VARIANT")) c->kernel_variant = std::min(2, std::max(0, atoi(ev)));
     if (const char *ev = getenv("SRT_DUO_MIN_TILES")) c->duo_min_tiles = (uint32_t)std::max(0, atoi(ev));
     if (const char *ev = getenv("SRT_DUO_W_SWAP")) c->duo_w_swap = (uint32_t)std::max(1, atoi(ev));
@@ -355,7 +360,8 @@ int srt_render_chunk(srt_ctx *c, uint32_t width, uint32_t height, uint32_t offx,
         HIP_TRY(c, hipMalloc((void **)&c->d_tiles, need * sizeof(float)));
         c->tiles_capacity = need;
     }
-    HIP_TRY(c, hipMemsetAsync(c->d_tiles, 0, need * sizeof(float), st));
+    // (only the plane groups this launch writes: group 0, or all three when the parity planes were asked for)
+    HIP_TRY(c, hipMemsetAsync(c->d_tiles, 0, (size_t)std::max<uint32_t>(c->tiles_padded, 1) * c->gather_planes * kTileLanes * sizeof(float), st));
     HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, (kCounters + 1) * sizeof(unsigned long long), st));
     RenderParams p;
     fill_params(c, p);
@@ -394,19 +400,19 @@ int srt_render_chunk(srt_ctx *c, uint32_t width, uint32_t height, uint32_t offx,
         if (c->tiles_local > c->tile_sched_capacity) {
             if (c->d_tile_cost) { (void)hipFree(c->d_tile_cost); c->d_tile_cost = nullptr; }
             if (c->d_tile_order) { (void)hipFree(c->d_tile_order); c->d_tile_order = nullptr; }
-            HIP_TRY(c, hipMalloc((void **)&c->d_tile_cost, c->tiles_local * sizeof(uint32_t)));
+            HIP_TRY(c, hipMalloc((void **)&c->d_tile_cost, 2 * (size_t)c->tiles_local * sizeof(uint32_t)));      // cost | most expensive pixel
             // [rows: up to 64 per tile][sorted tile ids][queue_info]
             HIP_TRY(c, hipMalloc((void **)&c->d_tile_order, ((size_t)c->tiles_local * 65 + 4) * sizeof(uint32_t)));
             c->tile_sched_capacity = c->tiles_local;
         }
         uint32_t *rows = c->d_tile_order, *sorted = rows + (size_t)c->tile_sched_capacity * 64, *queue_info = sorted + c->tile_sched_capacity;
-        HIP_TRY(c, hipMemsetAsync(c->d_tile_cost, 0, c->tiles_local * sizeof(uint32_t), st));
+        HIP_TRY(c, hipMemsetAsync(c->d_tile_cost, 0, 2 * (size_t)c->tiles_local * sizeof(uint32_t), st));
         RenderParams pp = p;
         pp.spp = c->probe_spp; pp.tile_cost = c->d_tile_cost;
         RoctxRange range_probe("srt cost probe + pixel queue");
         HIP_TRY(c, launch_render(pp, (uint32_t)c->n_cu, 2, st));
         const uint32_t split_pct = use_duo ? 0u : c->split_load_pct;
-        HIP_TRY(c, launch_order_tiles(c->d_tile_cost, sorted, rows, c->tiles_local, (uint32_t)c->n_cu * (uint32_t)plan.waves_per_cu, split_pct, queue_info, st));   // device-side, no host sync
+        HIP_TRY(c, launch_order_tiles(c->d_tile_cost, sorted, rows, c->tiles_local, (uint32_t)c->n_cu * (uint32_t)plan.waves_per_cu, split_pct, queue_info, c->order_max_pct, c->split_by_key, st));   // device-side, no host sync
         HIP_TRY(c, hipMemsetAsync(c->d_counters + kCounters, 0, sizeof(unsigned long long), st));   // rewind the queue head
         p.tile_order = rows;
         p.queue_rows = queue_info;
@@ -462,8 +468,7 @@ int srt_scatter_tiles(srt_ctx *c, const void *dev_gathered, void *stream) {
     uint32_t groups = c->gather_planes / (uint32_t)kGroupPlanes;
     if (!dev_gathered) {
         if (c->world != 1) return fail(c, SRT_ERR_INVALID, "srt_scatter_tiles: a gathered buffer is required when world > 1");
-        dev_gathered = c->d_tiles;
-        groups = (uint32_t)kTileGroups;      // the context's own tile buffer always holds all nine planes
+        dev_gathered = c->d_tiles;      // the context's own tile buffer: group 0, and the parity groups when they were asked for
     }
     HIP_TRY(c, hipSetDevice(c->device));
     ScatterParams sp;

@@ -47,7 +47,7 @@ struct RenderParams {
     uint32_t tiles_local;                 // number of tiles this rank owns (pixel queue length / 64)
     uint32_t *pixel_counter;              // device word, zeroed before the launch: head of the pixel queue
     const uint32_t *tile_order;           // optional: queue slot -> local tile (cost-descending order); null = identity
-    uint32_t *tile_cost;                  // probe mode: per local tile, node records visited by its pixels
+    uint32_t *tile_cost;                  // probe mode: [0, tiles_local) per local tile, node records visited by its pixels; [tiles_local, 2 tiles_local) its most expensive pixel
     const uint32_t *queue_rows;           // optional: [0] = number of queue rows, [1] = the largest tile cost (device-written by order_tiles_kernel)
     const uint32_t *prio_cost;            // optional: the probe's per-tile cost, read by the render launch for its wave priorities
     uint32_t queue_rows_bound;            // host-side upper bound of the row count (= tiles_local without splitting)
@@ -62,6 +62,7 @@ struct RenderParams {
     uint32_t n_lanes;                     // tx*ty*bx*by
     float *tile_out;                      // [group][local tile (tiles_padded of them)][plane of the group][lane]
     uint32_t tile_group_stride;           // floats between two groups = tiles_padded * 3 * 64
+    uint32_t write_parity;                // 0: only group 0 (the reference's framebuffer values) is written; 1: + the two parity groups
     unsigned long long *counters;
     uint32_t *wave_debug;                 // instrumented build, optional: 4 words per wave (see srt_get_wave_debug)
 };
@@ -82,7 +83,7 @@ bool render_duo_eligible(int stack_depth, int n_records, int n_inner, int root_r
 size_t render_duo_lds_bytes(int stack_depth, int n_inner);
 hipError_t launch_render_duo(const RenderParams &p, uint32_t n_cu, hipStream_t st);
 hipError_t launch_order_tiles(const uint32_t *cost, uint32_t *sorted, uint32_t *rows, uint32_t n, uint32_t n_waves,
-                              uint32_t split_load_pct, uint32_t *queue_info, hipStream_t st);
+                              uint32_t split_load_pct, uint32_t *queue_info, uint32_t order_max_pct, uint32_t split_by_key, hipStream_t st);
 hipError_t launch_scatter(const ScatterParams &p, hipStream_t st);
 hipError_t launch_unswizzle(const float *const src[3], float *const dst[3], uint32_t tx, uint32_t ty, uint32_t bx, uint32_t by,
                             uint32_t n_cols, uint32_t n_rows, uint32_t offx, uint32_t offy, uint32_t image_width,

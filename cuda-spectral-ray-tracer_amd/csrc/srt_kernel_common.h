@@ -23,6 +23,8 @@ struct LdsUniforms {
     uint32_t lane_limit;
     uint32_t rng[2], tile_out[2], tile_order[2], tile_cost[2], pixel_counter[2];
     uint32_t tile_group_stride;
+    uint32_t first_row_taken;       // bit w: wave w of this workgroup has taken its assigned first row
+    uint32_t n_assigned_slots;      // queue slots handed out by assignment (the first row of every wave): the shared counter starts behind them
     uint32_t prio_cost[2], prio_full;      // per-tile probe cost (read-only in the render launch) and cost_max * spp (as float bits)
 };
 static_assert(sizeof(LdsUniforms) <= kLdsUniF4 * 16, "uniform block too large");
@@ -38,6 +40,12 @@ constexpr size_t kLdsBudget = 160 * 1024;
 
 #ifndef SRT_PRIO_MODE
 #define SRT_PRIO_MODE 1      /* wave priorities by remaining chain length (least slack first), see render_kernel */
+#endif
+#ifndef SRT_ASSIGN_FIRST_ROW
+#define SRT_ASSIGN_FIRST_ROW 1   /* the first queue row of every wave is assigned by cost band instead of raced for (render_kernel, S3) */
+#endif
+#ifndef SRT_PRIO_L2
+#define SRT_PRIO_L2 0        /* 1: the priorities are also compiled into the variants whose inner tree is partly served by L2 */
 #endif
 #ifndef SRT_PRIO_T1
 #define SRT_PRIO_T1 256      /* tiers: remaining chain > T / 1024 of the longest chain of the launch */

@@ -138,6 +138,8 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
         split_ptr(P.rng, U->rng); split_ptr(P.tile_out, U->tile_out); split_ptr(P.tile_order, U->tile_order);
         split_ptr(P.tile_cost, U->tile_cost); split_ptr(P.pixel_counter, U->pixel_counter);
         U->tile_group_stride = P.tile_group_stride;
+        U->n_assigned_slots = gridDim.x * (blockDim.x >> 6) * 64u;      // one assigned first row per launched wave
+        U->first_row_taken = 0u;
         split_ptr(P.prio_cost, U->prio_cost);
         U->prio_full = __float_as_uint(P.queue_rows && P.prio_cost ? (float)P.queue_rows[1] * (float)P.spp : 0.f);
     }
@@ -336,11 +338,15 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
             }
 
             // ---- S3: pixel switch: all samples of the current pixel done (or no pixel yet) ------------------------
-            const bool switched_any = SRT_PRIO_MODE != 0 && ALL_CACHED && __ballot(!dead && !parked && tv.node < 0 && !have_path && !begin_trav && (!have_pixel || sample == spp)) != 0ull;
+            const bool switched_any = SRT_PRIO_MODE != 0 && (ALL_CACHED || SRT_PRIO_L2) && __ballot(!dead && !parked && tv.node < 0 && !have_path && !begin_trav && (!have_pixel || sample == spp)) != 0ull;
             if (!dead && !parked && tv.node < 0 && !have_path && !begin_trav && (!have_pixel || sample == spp)) {
                 if (have_pixel && PROBE) {
                     // cost of this pixel = node records it visited (+1 so that empty pixels still sort after real ones)
-                    atomicAdd(join_ptr<uint32_t>(U->tile_cost[0], U->tile_cost[1]) + cur_tile_local, ts.n_iters - pixel_iters0 + 1u);
+                    uint32_t *tcost = join_ptr<uint32_t>(U->tile_cost[0], U->tile_cost[1]);
+                    atomicAdd(tcost + cur_tile_local, ts.n_iters - pixel_iters0 + 1u);
+                    // ... and the tile's most expensive pixel (second half of the array): a pixel is one sequential chain, and a tile
+                    // of average cost may hold a few very long ones (the silhouette of a glass object); order_tiles_kernel can rank by it
+                    atomicMax(tcost + P.tiles_local + cur_tile_local, ts.n_iters - pixel_iters0 + 1u);
                     have_pixel = false;
                 }
                 if (have_pixel && COUNT) { max_pix_iters = max(max_pix_iters, ts.n_iters - pixel_iters0); max_pix_rays = max(max_pix_rays, n_rays - pixel_rays0); }
@@ -366,8 +372,10 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
                     o[0 * kTileLanes] = (float)(int)(r * 255.99f);      // expand_sRGB (color.cu:43-49, Q15)
                     o[1 * kTileLanes] = (float)(int)(g * 255.99f);
                     o[2 * kTileLanes] = (float)(int)(b * 255.99f);
-                    o[gs + 0 * kTileLanes] = r; o[gs + 1 * kTileLanes] = g; o[gs + 2 * kTileLanes] = b;
-                    o[2 * gs + 0 * kTileLanes] = acc.x; o[2 * gs + 1 * kTileLanes] = acc.y; o[2 * gs + 2 * kTileLanes] = acc.z;
+                    if (P.write_parity) {      // (only when the caller asked for the parity planes: srt_set_gather_planes(ctx, 9))
+                        o[gs + 0 * kTileLanes] = r; o[gs + 1 * kTileLanes] = g; o[gs + 2 * kTileLanes] = b;
+                        o[2 * gs + 0 * kTileLanes] = acc.x; o[2 * gs + 1 * kTileLanes] = acc.y; o[2 * gs + 2 * kTileLanes] = acc.z;
+                    }
                     have_pixel = false;
                 }
                 // fetch the next pixel of this rank's queue (wave-aggregated atomic); skip slots outside the chunk
@@ -377,8 +385,21 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
                     const unsigned long long m = __ballot(1);
                     const int leader = __ffsll((long long)m) - 1;
                     uint32_t base = 0;
-                    if ((int)lane == leader) base = atomicAdd(join_ptr<uint32_t>(U->pixel_counter[0], U->pixel_counter[1]), (uint32_t)__popcll(m));
-                    base = (uint32_t)__shfl((int)base, leader, 64);
+                    // The FIRST row of every wave is assigned, not raced for: wave w of workgroup b takes row w * (number of
+                    // workgroups) + b of the cost-descending queue, so every CU -- and, with consecutive waves of a workgroup on
+                    // different SIMDs, every SIMD -- starts with one row of each cost band instead of sixteen neighbours of the
+                    // sorted order (the most expensive tiles of a launch used to share a handful of CUs for their whole life), and
+                    // the placement no longer depends on the order in which the waves' first atomics arrive.  Later rows come
+                    // from the shared counter, which starts behind the assigned ones.
+                    const bool assigned = SRT_ASSIGN_FIRST_ROW != 0 && m == ~0ull && ((U->first_row_taken >> wave) & 1u) == 0u;
+                    if (assigned) {      // (the per-wave "taken" bit lives in LDS: nothing stays live in the persistent loop for it)
+                        if (lane == 0) atomicOr((unsigned int *)&U->first_row_taken, 1u << wave);
+                        base = (wave * gridDim.x + blockIdx.x) * 64u;
+                    }
+                    else {
+                        if ((int)lane == leader) base = atomicAdd(join_ptr<uint32_t>(U->pixel_counter[0], U->pixel_counter[1]), (uint32_t)__popcll(m));
+                        base = (uint32_t)__shfl((int)base, leader, 64) + (SRT_ASSIGN_FIRST_ROW != 0 ? U->n_assigned_slots : 0u);
+                    }
                     const uint32_t pix = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
                     if (pix >= U->n_rows * 64u) { dead = true; searching = false; if (COUNT && t_dry == 0) t_dry = __builtin_amdgcn_s_memtime(); }
                     else {
@@ -446,7 +467,7 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
             // whenever a lane of the wave switched pixel.  Not compiled into the variant for trees served by L2: that one is
             // memory-bound, the priorities cost it 1.5-2 % on a full frame and return 2 % on one rank's share of an 8-rank frame.
             // Scheduling only: results do not depend on it.
-            if (!PROBE && ALL_CACHED && switched_any) {
+            if (!PROBE && (ALL_CACHED || SRT_PRIO_L2) && switched_any) {
                 float rem = 0.f;
                 const uint32_t *tc = join_ptr<const uint32_t>(U->prio_cost[0], U->prio_cost[1]);
                 if (tc && have_pixel && !dead) rem = (float)tc[out_slot / (uint32_t)(kGroupPlanes * kTileLanes)] * (float)(spp - sample);
@@ -648,7 +669,7 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
 //    queue row = tile | part << 22 | s << 28;  queue_info[0] = number of rows.
 __global__ __launch_bounds__(1024) void order_tiles_kernel(const uint32_t *__restrict__ cost, uint32_t *__restrict__ sorted,
                                                           uint32_t *__restrict__ rows, uint32_t n, uint32_t n_waves,
-                                                          uint32_t split_load_pct, uint32_t *__restrict__ queue_info) {
+                                                          uint32_t split_load_pct, uint32_t *__restrict__ queue_info, uint32_t order_max_pct, uint32_t split_by_key) {
     constexpr uint32_t kBinsN = 4096;
     __shared__ uint32_t s_bin[kBinsN];
     __shared__ uint32_t s_max;
@@ -659,22 +680,36 @@ __global__ __launch_bounds__(1024) void order_tiles_kernel(const uint32_t *__res
     if (t == 0) { s_max = 1u; s_sum = 0ull; }
     for (uint32_t b = t; b < kBinsN; b += 1024) s_bin[b] = 0u;
     __syncthreads();
-    uint32_t m = 0;
+    // Sort key of a tile: its cost (sum over its 64 pixels) moved order_max_pct % of the way towards 64 x its most expensive pixel
+    // (cost[n + k], the probe's second array).  0: longest-processing-time-first by tile cost; 100: tiles holding the longest single
+    // chains first, whatever the rest of the tile costs.  The split policy and the wave priorities below keep using the cost.
+    auto key_of = [&](uint32_t k) -> uint32_t {
+        const uint32_t c = cost[k];
+        if (order_max_pct == 0u) return c;
+        const unsigned long long mx64 = (unsigned long long)cost[n + k] * 64ull;
+        const unsigned long long key = mx64 > c ? c + (mx64 - c) * order_max_pct / 100ull : c;
+        return key > 0xffffffffull ? 0xffffffffu : (uint32_t)key;
+    };
+    __shared__ uint32_t s_kmax;
+    if (t == 0) s_kmax = 1u;
+    uint32_t m = 0, km = 0;
     unsigned long long sum = 0;
-    for (uint32_t k = t; k < n; k += 1024) { m = max(m, cost[k]); sum += cost[k]; }
+    for (uint32_t k = t; k < n; k += 1024) { m = max(m, cost[k]); km = max(km, key_of(k)); sum += cost[k]; }
     atomicMax(&s_max, m);
     atomicAdd(&s_sum, sum);
     __syncthreads();
-    const float scale = (float)(kBinsN - 1) / (float)s_max;
+    atomicMax(&s_kmax, km);
+    __syncthreads();
+    const float scale = (float)(kBinsN - 1) / (float)s_kmax;
     auto bin_of = [&](uint32_t c) { uint32_t b = (uint32_t)((float)c * scale); b = b > kBinsN - 1 ? kBinsN - 1 : b; return (kBinsN - 1) - b; };   // bin 0 = most expensive
-    for (uint32_t k = t; k < n; k += 1024) atomicAdd(&s_bin[bin_of(cost[k])], 1u);
+    for (uint32_t k = t; k < n; k += 1024) atomicAdd(&s_bin[bin_of(key_of(k))], 1u);
     __syncthreads();
     if (t == 0) {       // exclusive scan of 4096 counters: trivial next to the render
         uint32_t acc = 0;
         for (uint32_t b = 0; b < kBinsN; b++) { const uint32_t c = s_bin[b]; s_bin[b] = acc; acc += c; }
     }
     __syncthreads();
-    for (uint32_t k = t; k < n; k += 1024) sorted[atomicAdd(&s_bin[bin_of(cost[k])], 1u)] = k;
+    for (uint32_t k = t; k < n; k += 1024) sorted[atomicAdd(&s_bin[bin_of(key_of(k))], 1u)] = k;
     __syncthreads();
 
     // latency of a tile relative to the same tile at 64 pixels per wave, by split level (pixels per wave 64 .. 1)
@@ -693,15 +728,19 @@ __global__ __launch_bounds__(1024) void order_tiles_kernel(const uint32_t *__res
     // latency with wave-slot time (a tile cut into 64 single-pixel rows costs 28x its unsplit slot time), so (b) is what
     // keeps a throughput-bound launch from splitting anything.  Bisection; every step is one parallel reduction.
     // (also keeps 64 * rows far below 2^32: the queue head is a 32-bit pixel-slot counter)
+    // latency estimate of a tile for the split policy: its cost, or (split_by_key) the sort key -- which weighs the tile's longest
+    // single chain: a tile of average cost that holds one very long pixel is as late as a tile of 64 such pixels
+    auto lat_of = [&](uint32_t k) -> uint32_t { return split_by_key ? key_of(k) : cost[k]; };
     const bool may_split = split_load_pct != 0u && n <= (1u << 20);
     float target = 3.0e38f;
     if (may_split) {
         const float load_factor = (float)split_load_pct * 0.01f;
-        float lo_t = (float)s_max * g[6], hi_t = fmaxf((float)s_max, load_factor * (float)s_sum / (float)(n_waves ? n_waves : 1u));
+        const float lat_max = (float)(split_by_key ? s_kmax : s_max);
+        float lo_t = lat_max * g[6], hi_t = fmaxf(lat_max, load_factor * (float)s_sum / (float)(n_waves ? n_waves : 1u));
         for (int it = 0; it < 14; it++) {
             const float mid = 0.5f * (lo_t + hi_t);
             float load = 0.f;
-            for (uint32_t k = t; k < n; k += 1024) { const uint32_t c = cost[k]; const uint32_t s = level_for(c, mid); load += (float)(1u << s) * (float)c * g[s]; }
+            for (uint32_t k = t; k < n; k += 1024) { const uint32_t c = lat_of(k); const uint32_t s = level_for(c, mid); load += (float)(1u << s) * (float)c * g[s]; }
             if (t == 0) s_load = 0.f;
             __syncthreads();
             atomicAdd(&s_load, load);
@@ -712,12 +751,12 @@ __global__ __launch_bounds__(1024) void order_tiles_kernel(const uint32_t *__res
         }
         target = hi_t;
     }
-    auto level_of = [&](uint32_t c) { return may_split ? level_for(c, target) : 0u; };
+    auto level_of = [&](uint32_t k) { return may_split ? level_for(lat_of(k), target) : 0u; };
     // rows per thread over a contiguous piece of the sorted order, then a scan
     const uint32_t per = (n + 1023u) / 1024u;
     const uint32_t lo = min(n, t * per), hi = min(n, lo + per);
     uint32_t mine = 0;
-    for (uint32_t k = lo; k < hi; k++) mine += 1u << level_of(cost[sorted[k]]);
+    for (uint32_t k = lo; k < hi; k++) mine += 1u << level_of(sorted[k]);
     s_scan[t] = mine;
     __syncthreads();
     if (t == 0) {
@@ -729,7 +768,7 @@ __global__ __launch_bounds__(1024) void order_tiles_kernel(const uint32_t *__res
     __syncthreads();
     uint32_t at = s_scan[t];
     for (uint32_t k = lo; k < hi; k++) {
-        const uint32_t tile = sorted[k], s = level_of(cost[tile]);
+        const uint32_t tile = sorted[k], s = level_of(tile);
         for (uint32_t part = 0; part < (1u << s); part++) rows[at++] = tile | (part << 22) | (s << 28);
     }
 }
@@ -904,9 +943,9 @@ hipError_t launch_render(const RenderParams &p, uint32_t n_cu, int mode, hipStre
 }
 
 hipError_t launch_order_tiles(const uint32_t *cost, uint32_t *sorted, uint32_t *rows, uint32_t n, uint32_t n_waves,
-                              uint32_t split_load_pct, uint32_t *queue_info, hipStream_t st) {
+                              uint32_t split_load_pct, uint32_t *queue_info, uint32_t order_max_pct, uint32_t split_by_key, hipStream_t st) {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(order_tiles_kernel, dim3(1), dim3(1024), 0, st, cost, sorted, rows, n, n_waves, split_load_pct, queue_info);
+    hipLaunchKernelGGL(order_tiles_kernel, dim3(1), dim3(1024), 0, st, cost, sorted, rows, n, n_waves, split_load_pct, queue_info, order_max_pct, split_by_key);
     return hipGetLastError();
 }
 

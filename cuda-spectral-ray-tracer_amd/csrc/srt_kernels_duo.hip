@@ -68,6 +68,8 @@ __global__ __launch_bounds__(768) void render_kernel_duo(const RenderParams P) {
         split_ptr(P.rng, U->rng); split_ptr(P.tile_out, U->tile_out); split_ptr(P.tile_order, U->tile_order);
         split_ptr(P.tile_cost, U->tile_cost); split_ptr(P.pixel_counter, U->pixel_counter);
         U->tile_group_stride = P.tile_group_stride;
+        U->n_assigned_slots = gridDim.x * (blockDim.x >> 6) * 64u;      // one assigned first row per launched wave
+        U->first_row_taken = 0u;
         split_ptr(P.prio_cost, U->prio_cost);
         U->prio_full = __float_as_uint(P.queue_rows && P.prio_cost ? (float)P.queue_rows[1] * (float)P.spp : 0.f);
     }
@@ -128,8 +130,16 @@ __global__ __launch_bounds__(768) void render_kernel_duo(const RenderParams P) {
     Trav tv; tv.node = kTravIdle; tv.sp = 0u; tv.top = -1; tv.c = kFltMax; tv.hit = -1; tv.nf[0] = tv.nf[1] = tv.nf[2] = 0u;
     TravStats ts;
     uint32_t n_rays = 0;
+#ifdef SRT_DUO_STATS
+    // experiment build (tools/build_variant.sh duostats -DSRT_DUO_STATS): wave-level event counts, read back through srt_get_stats
+    uint32_t q_iter = 0, q_swap = 0, q_swap_l = 0, q_d = 0, q_d_l = 0, q_g = 0, q_g_l = 0, q_e = 0, q_e_l = 0, q_blk = 0, q_fr = 0, q_fr_l = 0, q_asm = 0, q_trav_l = 0, q_cam_l = 0;
+#define SRT_Q(x) x
+#else
+#define SRT_Q(x)
+#endif
 
     for (;;) {
+        SRT_Q(q_iter++;)
         // =========================== service phase ==================================================================
         // Which S contexts wait for which pass.  A lane is BLOCKED when its A side has nothing to walk and its S side must be
         // shaded before it can take over.
@@ -151,6 +161,7 @@ __global__ __launch_bounds__(768) void render_kernel_duo(const RenderParams P) {
             const uint32_t n_fr = (uint32_t)__popcll(m_fr), n_in = (uint32_t)__popcll(m_trav) - n_fr;
             const uint32_t trav_score = max(n_fr * w_fringe, n_in << 8);
             const bool urgent = (uint32_t)__popcll(m_blocked) * w_blk > trav_score || m_trav == 0ull;
+            SRT_Q(q_blk += (uint32_t)__popcll(m_blocked);)
             const bool run_d = (uint32_t)__popcll(m_d) >= t_d || (urgent && (m_d & m_blocked) != 0ull);
             const bool run_g = (uint32_t)__popcll(m_g) >= t_g || (urgent && (m_g & m_blocked) != 0ull);
             const bool run_e = (uint32_t)__popcll(m_e) >= t_e || (urgent && (m_e & m_blocked) != 0ull);
@@ -162,6 +173,7 @@ __global__ __launch_bounds__(768) void render_kernel_duo(const RenderParams P) {
             for (int pass = 0; pass < 2; pass++) {
                 const bool go = pass == 0 ? (run_d && want_d) : (run_g && want_g);
                 if (__ballot(go) == 0ull) continue;
+                SRT_Q(if (pass == 0) { q_d++; q_d_l += (uint32_t)__popcll(__ballot(go)); } else { q_g++; q_g_l += (uint32_t)__popcll(__ballot(go)); })
                 if (go) {
                     float wl[kWavelengths];
                     hero_expand(hero, wl);
@@ -248,6 +260,7 @@ __global__ __launch_bounds__(768) void render_kernel_duo(const RenderParams P) {
             // ---- pass E: path end, pixel switch, next camera ray ----------------------------------------------------------
             if (run_e && __ballot(want_e) != 0ull) {
                 bool switched = false;
+                SRT_Q(q_e++; q_e_l += (uint32_t)__popcll(__ballot(want_e));)
                 if (want_e) {
                     // E1: a miss multiplies the background into the path (rendering.cu:24-27), an emissive hit its own spectrum
                     // (material.cu:83-86,95); then pixel_color += dev_spectrum_to_XYZ(...) (rendering.cu:227, color.cu:88-104)
@@ -306,8 +319,10 @@ __global__ __launch_bounds__(768) void render_kernel_duo(const RenderParams P) {
                             o[0 * kTileLanes] = (float)(int)(r * 255.99f);      // expand_sRGB (color.cu:43-49, Q15)
                             o[1 * kTileLanes] = (float)(int)(g * 255.99f);
                             o[2 * kTileLanes] = (float)(int)(b * 255.99f);
-                            o[gs + 0 * kTileLanes] = r; o[gs + 1 * kTileLanes] = g; o[gs + 2 * kTileLanes] = b;
-                            o[2 * gs + 0 * kTileLanes] = acc.x; o[2 * gs + 1 * kTileLanes] = acc.y; o[2 * gs + 2 * kTileLanes] = acc.z;
+                            if (P.write_parity) {
+                                o[gs + 0 * kTileLanes] = r; o[gs + 1 * kTileLanes] = g; o[gs + 2 * kTileLanes] = b;
+                                o[2 * gs + 0 * kTileLanes] = acc.x; o[2 * gs + 1 * kTileLanes] = acc.y; o[2 * gs + 2 * kTileLanes] = acc.z;
+                            }
                         }
                         st_s = kStEmpty;
                         // fetch the next pixel of this rank's queue (wave-aggregated atomic); skip slots outside the chunk
@@ -316,8 +331,16 @@ __global__ __launch_bounds__(768) void render_kernel_duo(const RenderParams P) {
                             const unsigned long long m = __ballot(1);
                             const int leader = __ffsll((long long)m) - 1;
                             uint32_t base = 0;
-                            if ((int)lane == leader) base = atomicAdd(join_ptr<uint32_t>(U->pixel_counter[0], U->pixel_counter[1]), (uint32_t)__popcll(m));
-                            base = (uint32_t)__shfl((int)base, leader, 64);
+                            // the first row of a wave is assigned (spread over the CUs by cost band), later ones come from the counter: see render_kernel
+                            const bool assigned = SRT_ASSIGN_FIRST_ROW != 0 && m == ~0ull && ((U->first_row_taken >> wave) & 1u) == 0u;
+                            if (assigned) {
+                                if (lane == 0) atomicOr((unsigned int *)&U->first_row_taken, 1u << wave);
+                                base = (wave * gridDim.x + blockIdx.x) * 64u;
+                            }
+                            else {
+                                if ((int)lane == leader) base = atomicAdd(join_ptr<uint32_t>(U->pixel_counter[0], U->pixel_counter[1]), (uint32_t)__popcll(m));
+                                base = (uint32_t)__shfl((int)base, leader, 64) + (SRT_ASSIGN_FIRST_ROW != 0 ? U->n_assigned_slots : 0u);
+                            }
                             const uint32_t pix = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
                             if (pix >= U->n_rows * 64u) { st_s = kStDead; searching = false; }
                             else {
@@ -371,6 +394,7 @@ __global__ __launch_bounds__(768) void render_kernel_duo(const RenderParams P) {
                 }
 #endif
                 // E3: new camera ray: renderer::get_ray (rendering.cu:66-87)
+                SRT_Q(q_cam_l += (uint32_t)__popcll(__ballot(want_e && st_s == kStNeedSample && sample < spp));)
                 if (want_e && st_s == kStNeedSample && sample < spp) {
                     float px = -0.5f + rng_uniform(rs);                       // pixel_sample_square, :49-56
                     float py = -0.5f + rng_uniform(rs);
@@ -413,6 +437,7 @@ __global__ __launch_bounds__(768) void render_kernel_duo(const RenderParams P) {
         {
             const bool do_swap = tv.node < 0 && (st_s == kStRay || (st_s == kStDead && st_a == kStRay));
             if (__ballot(do_swap) != 0ull) {
+                SRT_Q(q_swap++; q_swap_l += (uint32_t)__popcll(__ballot(do_swap));)
                 if (do_swap) {
 // (v_swap_b32 by hand: left to the compiler, the exchange became ~180 v_mov through temporaries)
 #define SRT_SWAP(a, b) asm volatile("v_swap_b32 %0, %1" : "+v"(a), "+v"(b));
@@ -448,7 +473,9 @@ __global__ __launch_bounds__(768) void render_kernel_duo(const RenderParams P) {
             const unsigned long long alive = __ballot(!dead2);
             if (alive == 0ull) break;
             const unsigned long long spend = __ballot(st_s == kStRay || st_s == kStDead);
+            SRT_Q(q_asm++; q_trav_l += (uint32_t)__popcll(__ballot(tv.node >= 0));)
             while (inner_phase_duo_asm(tv, ns, ro_a, inv_a, n_inner_u, alive, spend, w_swap, w_blk, w_fringe) != 0u) {
+                SRT_Q(q_fr++; q_fr_l += (uint32_t)__popcll(__ballot(tv.node >= (int)n_inner_u));)
                 if (tv.node >= (int)n_inner_u) trav_step_fringe<false, true>(tv, ns, ro_a, rd_a, inv_a, my_stack, ts);
             }
         }
@@ -457,6 +484,12 @@ __global__ __launch_bounds__(768) void render_kernel_duo(const RenderParams P) {
     {
         uint32_t r = wave_sum(n_rays);
         if (lane == 0 && r) atomicAdd(&P.counters[0], (unsigned long long)r);
+#ifdef SRT_DUO_STATS
+        if (lane == 0) {
+            const uint32_t q[15] = {q_iter, q_swap, q_swap_l, q_d, q_d_l, q_g, q_g_l, q_e, q_e_l, q_blk, q_fr, q_fr_l, q_asm, q_trav_l, q_cam_l};
+            for (int k = 0; k < 15; k++) atomicAdd(&P.counters[1 + k], (unsigned long long)q[k]);
+        }
+#endif
     }
 }
 

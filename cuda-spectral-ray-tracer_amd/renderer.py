@@ -26,6 +26,7 @@ class Renderer:
             self._h, self._owned = h, True
             self.device = device
         self.geom = None
+        self.gather_planes = 3
 
     def close(self):
         if getattr(self, "_h", None):
@@ -85,6 +86,7 @@ class Renderer:
     def set_gather_planes(self, planes):
         """3 (default): the exchange unit is the quantised framebuffer; 9: + the parity planes (unquantised sRGB, XYZ sums)"""
         self._ck(B.lib().srt_set_gather_planes(self._h, planes))
+        self.gather_planes = planes
 
     def tile_buffer(self):
         ptr, n, tl, tp = C.c_void_p(), C.c_size_t(), C.c_uint32(), C.c_uint32()
@@ -258,6 +260,8 @@ class Comm:
 
     def set_gather_planes(self, planes):
         self._ck(B.lib().srt_comm_set_gather_planes(self._h, planes))
+        for r in self.renderers:
+            r.gather_planes = planes
 
     def last_gather_ms(self):
         ms = C.c_float()
@@ -287,10 +291,13 @@ def render_image(scene, cam, width, height, spp, bounce_limit, seed=1984, device
     r.set_count_traversal(count_traversal)
     if variant is not None:
         r.set_kernel_variant(variant)
+    planes_before = r.gather_planes
+    r.set_gather_planes(9)            # the parity planes (unquantised sRGB, XYZ sums) are part of what this returns
     r.render_chunk(width, height, 0, 0)
     r.scatter_tiles()
     if variant is not None:
         r.set_kernel_variant(0)
+    r.set_gather_planes(planes_before)
     out = dict(variant=r.last_kernel_variant(), fb=r.read_fb(), lin=r.read_fb_aux(1), xyz=r.read_fb_aux(2), rowmajor=r.read_fb_rowmajor(width, height),
                stats=r.stats(), kernel_ms=r.last_kernel_ms(), geom=dict(r.geom))
     if renderer is None:

@@ -220,9 +220,10 @@ SRT_API int srt_synchronize(srt_ctx *ctx);
 /* Compact tile buffer of this rank (device memory): three plane GROUPS of tiles_padded * 3 * 64 floats each,
  * [group][tile][plane][lane] -- group 0 = quantised r,g,b (the reference's frame_buffer values, 12 B / pixel), group 1 =
  * unquantised sRGB r,g,b, group 2 = XYZ sums (parity planes).  tiles_padded = ceil(n_tiles/world), so every rank's buffer has
- * the same size.  The EXCHANGE UNIT of the multi-GPU gather is the first `planes` planes of it: 3 (default: what the
- * reference's framebuffer holds) or 9 (srt_set_gather_planes: parity tests that compare the XYZ sums of a
- * partitioned render).  srt_tile_buffer reports n_floats = tiles_padded * planes * 64. */
+ * the same size.  `planes` = 3 (default): the render kernel writes group 0 only, and group 0 is what a scatter / the multi-GPU
+ * gather moves -- what the reference's framebuffer holds; `planes` = 9: the kernel also writes the two parity groups
+ * and scatter / gather move all three (parity tests that compare unquantised sRGB or XYZ sums; srt_read_fb_aux needs it).  Set it
+ * before srt_render_chunk.  srt_tile_buffer reports n_floats = tiles_padded * planes * 64. */
 SRT_API int srt_set_gather_planes(srt_ctx *ctx, uint32_t planes);
 SRT_API int srt_tile_buffer(srt_ctx *ctx, void **dev_ptr, size_t *n_floats, uint32_t *tiles_local, uint32_t *tiles_padded);
 /* Stream-ordered device-to-device copy of the exchange unit into caller-owned device memory (e.g. the tensor that is
@@ -230,7 +231,7 @@ SRT_API int srt_tile_buffer(srt_ctx *ctx, void **dev_ptr, size_t *n_floats, uint
 SRT_API int srt_copy_tile_buffer(srt_ctx *ctx, void *dst_dev, void *stream);
 /* Scatter gathered exchange units (device pointer, world * tiles_padded * planes * 64 floats, rank-major) into this
  * context's block-linear planar framebuffer (rendering.cu:146-148 layout); with planes == 3 only the quantised planes are
- * written.  With world == 1 pass NULL: the context's own tile buffer (all nine planes) is scattered. */
+ * written.  With world == 1 pass NULL: the context's own tile buffer (its first `planes` planes) is scattered. */
 SRT_API int srt_scatter_tiles(srt_ctx *ctx, const void *dev_gathered, void *stream);
 
 /* renderer::getDevFBr/g/b (rendering.cuh:87-97): device pointers to the block-linear planes (tx*bx*ty*by floats). */

@@ -34,5 +34,6 @@ def orc():
 def gpu(srt):
     """One device context for the whole GPU session (tests run in one process)."""
     r = srt.Renderer(0)      # raises loudly if there is no GPU: no CPU fallback exists
+    r.set_gather_planes(9)   # parity suite: the kernels also write the unquantised sRGB / XYZ planes (default 3: the framebuffer only)
     yield r
     r.close()

@@ -1,5 +1,6 @@
 #!/bin/bash
-# PMC passes for the render kernel (run on the GPU box through gpurun).  Each --pmc set is its own run, with
+# PMC passes for the render kernel (run on the GPU box through gpurun).  KERNEL_FILTER (default "render_kernel<0") selects the
+# dispatches that are summed, e.g. KERNEL_FILTER=render_kernel_duo.  Each --pmc set is its own run, with
 # --kernel-trace only (no other trace domains), as MI355X_MICROARCH.md prescribes.  Usage: tools/pmc_passes.sh <outdir> [bench args]
 set -u
 OUT=${1:-gpurun_out/pmc}; shift || true
@@ -11,13 +12,13 @@ for SET in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_WAV
   i=$((i+1))
   timeout -k 10 300 rocprofv3 --pmc $SET --kernel-trace --output-format csv -d "$OUT/pass$i" -- python bench.py $ARGS > "$OUT/pass$i.json" 2> "$OUT/pass$i.err" || echo "pass $i failed"
 done
-python - "$OUT" <<'PY'
+python - "$OUT" "${KERNEL_FILTER:-render_kernel<0}" <<'PY'
 import csv, glob, sys, collections
-out = sys.argv[1]
+out = sys.argv[1]; flt = sys.argv[2]
 tot = collections.defaultdict(float); n = collections.defaultdict(int)
 for f in glob.glob(out + "/pass*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
-        if "render_kernel<0" in row["Kernel_Name"]:
+        if flt in row["Kernel_Name"]:
             tot[row["Counter_Name"]] += float(row["Counter_Value"]); n[row["Counter_Name"]] += 1
 with open(out + "/summary.txt", "w") as fh:
     for k in sorted(tot):

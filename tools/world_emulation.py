@@ -19,17 +19,21 @@ r.upload_scene(scene); r.set_camera(cam)
 r.set_partition(0, 1); r.init_device_params(a.width, a.height, 8, a.depth, 1984); r.render_chunk(a.width, a.height); r.synchronize()   # warm-up
 out = {}
 for W in [int(x) for x in a.worlds.split(",")]:
-    ms = []
+    ms, reps = [], []
     for rank in ([int(x) for x in a.ranks.split(',') if int(x) < W] if a.ranks else range(W)):
         r.set_partition(rank, W)
-        best = 1e30
+        best, every = 1e30, []
         for _ in range(a.reps):
             r.init_device_params(a.width, a.height, a.spp, a.depth, 1984)
             r.render_chunk(a.width, a.height); r.synchronize()
+            every.append(round(r.last_kernel_ms(), 1))
             best = min(best, r.last_kernel_ms())
-        ms.append(round(best, 1))
-    out[W] = {"per_rank_ms": ms, "max_ms": max(ms), "speedup_vs_1": None}
-    print("world %d: max %.1f ms, ranks %s" % (W, max(ms), ms), flush=True)
+        ms.append(round(best, 1)); reps.append(every)
+    # per repetition: the frame time is the slowest rank of THAT repetition
+    frame = [max(x[k] for x in reps) for k in range(a.reps)]
+    out[W] = {"per_rank_ms": ms, "max_ms": max(ms), "speedup_vs_1": None, "per_rank_all_reps": reps, "frame_ms_per_rep": frame,
+              "slowest_rank_per_rep": [max(range(len(reps)), key=lambda q: reps[q][k]) for k in range(a.reps)]}
+    print("world %d: max-of-best %.1f ms, frames per repetition %s, slowest rank per repetition %s, ranks (best) %s" % (W, max(ms), frame, out[W]["slowest_rank_per_rep"], ms), flush=True)
 base = out.get(1, {}).get("max_ms")
 for W in out:
     out[W]["speedup_vs_1"] = (base / out[W]["max_ms"]) if base else None
