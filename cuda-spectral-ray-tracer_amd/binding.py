@@ -88,8 +88,6 @@ PROTOTYPES = {
     "srt_set_camera": (_i, [_vp, C.POINTER(CameraData)]),
     "srt_launch_plan": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     "srt_launch_lds_bytes": (_i, [_vp, C.POINTER(_sz)]),
-    "srt_set_kernel_variant": (_i, [_vp, _i]),
-    "srt_last_kernel_variant": (_i, [_vp, C.POINTER(_i)]),
     "srt_init_device_params": (_i, [_vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _u64]),
     "srt_set_partition": (_i, [_vp, _u32, _u32]),
     "srt_render_chunk": (_i, [_vp, _u32, _u32, _u32, _u32, _vp]),

@@ -66,13 +66,6 @@ struct srt_ctx {
     uint64_t lanes_allocated = 0;                       // size of d_rng / d_fb in lanes
     float last_probe_ms = 0.f;
     bool count_traversal = false;
-    // which render kernel a production launch uses: 0 = auto (render_kernel_duo when the scene qualifies and the launch is
-    // throughput-bound: at least duo_min_tiles tiles per persistent wave), 1 = always render_kernel, 2 = render_kernel_duo whenever
-    // the scene qualifies (srt_set_kernel_variant; env SRT_KERNEL_VARIANT / SRT_DUO_MIN_TILES)
-    int kernel_variant = 0;
-    uint32_t duo_min_tiles = 0xffffffffu;      // (auto never picks the duo kernel until a measured threshold is set here)
-    uint32_t duo_w_swap = 320, duo_w_blocked = 70, duo_fill_d = 40, duo_fill_g = 24, duo_fill_e = 40;      // env SRT_DUO_W_SWAP, ..._W_BLOCKED, ..._FILL_D / _G / _E
-    int last_variant = 0;                 // what the last srt_render_chunk launched: 0 render_kernel, 1 render_kernel_duo
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
     uint64_t last_paths = 0;
@@ -175,13 +168,6 @@ int srt_create(int device, srt_ctx **out) {
     if (const char *ev = getenv("SRT_SPLIT_LOAD")) c->split_load_pct = (uint32_t)std::max(0, atoi(ev));
     if (const char *ev = getenv("SRT_SPLIT_BY_KEY")) c->split_by_key = atoi(ev) ? 1u : 0u;
     if (const char *ev = getenv("SRT_ORDER_MAX_PCT")) c->order_max_pct = (uint32_t)std::min(400, std::max(0, atoi(ev)));
-    if (const char *ev = getenv("SRT_KERNEL_VARIANT")) c->kernel_variant = std::min(2, std::max(0, atoi(ev)));
-    if (const char *ev = getenv("SRT_DUO_MIN_TILES")) c->duo_min_tiles = (uint32_t)std::max(0, atoi(ev));
-    if (const char *ev = getenv("SRT_DUO_W_SWAP")) c->duo_w_swap = (uint32_t)std::max(1, atoi(ev));
-    if (const char *ev = getenv("SRT_DUO_W_BLOCKED")) c->duo_w_blocked = (uint32_t)std::max(1, atoi(ev));
-    if (const char *ev = getenv("SRT_DUO_FILL_D")) c->duo_fill_d = (uint32_t)std::max(1, atoi(ev));
-    if (const char *ev = getenv("SRT_DUO_FILL_G")) c->duo_fill_g = (uint32_t)std::max(1, atoi(ev));
-    if (const char *ev = getenv("SRT_DUO_FILL_E")) c->duo_fill_e = (uint32_t)std::max(1, atoi(ev));
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->n_cu = prop.multiProcessorCount;
@@ -268,18 +254,6 @@ int srt_launch_plan(const srt_ctx *c, int *waves_per_cu, int *n_cached, int *all
     if (n_cached) *n_cached = plan.n_cached;
     if (all_cached) *all_cached = plan.all_cached ? 1 : 0;
     if (narrow_refs) *narrow_refs = c->n_records <= 32767 ? 1 : 0;
-    return SRT_OK;
-}
-
-int srt_set_kernel_variant(srt_ctx *c, int variant) {
-    if (!c || variant < 0 || variant > 2) return fail(c, SRT_ERR_INVALID, "srt_set_kernel_variant: variant must be 0 (auto), 1 (render_kernel) or 2 (render_kernel_duo)");
-    c->kernel_variant = variant;
-    return SRT_OK;
-}
-
-int srt_last_kernel_variant(const srt_ctx *c, int *variant) {
-    if (!c || !variant) return fail(nullptr, SRT_ERR_INVALID, "srt_last_kernel_variant: null argument");
-    *variant = c->last_variant;
     return SRT_OK;
 }
 
@@ -387,15 +361,6 @@ int srt_render_chunk(srt_ctx *c, uint32_t width, uint32_t height, uint32_t offx,
     p.tile_order = nullptr; p.tile_cost = nullptr; p.queue_rows = nullptr; p.queue_rows_bound = c->tiles_local;
     p.debug_lane_limit = c->debug_lane_limit;
     const bool ordered = c->probe_spp > 0 && c->spp > 4 * c->probe_spp && c->tiles_local > 1 && c->tiles_local <= 0x3fffffu;   // 22-bit tile field of a queue row
-    // The two-context kernel (srt_kernels_duo.hip) for launches that are throughput-bound: a pixel's chain advances at half speed
-    // when it shares its lane, so it needs many tiles per persistent wave; its queue rows are whole tiles (never split).
-    bool use_duo = false;
-    if (!c->count_traversal && c->kernel_variant != 1 && render_duo_eligible(c->stack_depth, c->n_records, c->n_inner, c->root_ref)) {
-        const uint64_t duo_waves = (uint64_t)c->n_cu * kDuoWavesPerBlock;
-        use_duo = c->kernel_variant == 2 || (uint64_t)c->tiles_local >= (uint64_t)c->duo_min_tiles * duo_waves;
-    }
-    p.duo_w_swap = c->duo_w_swap; p.duo_w_blocked = c->duo_w_blocked;
-    p.duo_fill_d = c->duo_fill_d; p.duo_fill_g = c->duo_fill_g; p.duo_fill_e = c->duo_fill_e;
     if (ordered) {
         if (c->tiles_local > c->tile_sched_capacity) {
             if (c->d_tile_cost) { (void)hipFree(c->d_tile_cost); c->d_tile_cost = nullptr; }
@@ -411,7 +376,7 @@ int srt_render_chunk(srt_ctx *c, uint32_t width, uint32_t height, uint32_t offx,
         pp.spp = c->probe_spp; pp.tile_cost = c->d_tile_cost;
         RoctxRange range_probe("srt cost probe + pixel queue");
         HIP_TRY(c, launch_render(pp, (uint32_t)c->n_cu, 2, st));
-        const uint32_t split_pct = use_duo ? 0u : c->split_load_pct;
+        const uint32_t split_pct = c->split_load_pct;
         HIP_TRY(c, launch_order_tiles(c->d_tile_cost, sorted, rows, c->tiles_local, (uint32_t)c->n_cu * (uint32_t)plan.waves_per_cu, split_pct, queue_info, c->order_max_pct, c->split_by_key, st));   // device-side, no host sync
         HIP_TRY(c, hipMemsetAsync(c->d_counters + kCounters, 0, sizeof(unsigned long long), st));   // rewind the queue head
         p.tile_order = rows;
@@ -431,9 +396,7 @@ int srt_render_chunk(srt_ctx *c, uint32_t width, uint32_t height, uint32_t offx,
     }
     RoctxRange range_render("srt render_kernel");
     HIP_TRY(c, hipEventRecord(c->ev0, st));     // ev0..ev1 bracket the render kernel alone (roofline.achieved)
-    if (use_duo) HIP_TRY(c, launch_render_duo(p, (uint32_t)c->n_cu, st));
-    else HIP_TRY(c, launch_render(p, (uint32_t)c->n_cu, c->count_traversal ? 1 : 0, st));
-    c->last_variant = use_duo ? 1 : 0;
+    HIP_TRY(c, launch_render(p, (uint32_t)c->n_cu, c->count_traversal ? 1 : 0, st));
     HIP_TRY(c, hipEventRecord(c->ev1, st));
     c->timed = true;
     c->last_paths = 0;   // filled by srt_get_stats from the tile ownership

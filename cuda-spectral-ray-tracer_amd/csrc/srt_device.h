@@ -613,11 +613,6 @@ __device__ __forceinline__ void inner_burst8_asm(Trav &tv, const NodeSrc &ns, V3
     "s_bcnt1_i32_b64 s86, exec\n\t"                                                                                      \
     "s_cmp_lt_u32 s86, s87\n\t"                                                                                          \
     "s_cbranch_scc1 .Lsrt_phase_burst_end%=\n\t"
-#define SRT_INNER_NEXT3_ASM                                                                                              \
-    "v_cmpx_gt_u32 vcc, %[ninner], %[node]\n\t"                                                                          \
-    "s_bcnt1_i32_b64 s86, exec\n\t"                                                                                      \
-    "s_cmp_lt_u32 s86, s87\n\t"                                                                                          \
-    "s_cbranch_scc1 .Lsrt_duo_burst_end%=\n\t"
 __device__ __forceinline__ uint32_t inner_phase_asm(Trav &tv, const NodeSrc &ns, V3 o, V3 inv, uint32_t n_inner, uint32_t n_alive,
                                                     uint32_t score_shade, uint32_t score_fringe) {
     const f2 p0 = mk2(o.x, o.y), p1 = mk2(o.z, inv.x), p2 = mk2(inv.y, inv.z);
@@ -665,72 +660,6 @@ __device__ __forceinline__ uint32_t inner_phase_asm(Trav &tv, const NodeSrc &ns,
           [wshade] "s"(score_shade), [wfringe] "s"(score_fringe)
         : "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114",
           "v115", "v116", "v117", "v118", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "vcc",
-          "scc", "memory");
-    return kind;
-}
-
-// The same block for the two-context ("duo") kernel (srt_kernels_duo.hip).  A lane there owns two pixels: context A's ray is the one
-// this block walks, context S waits for a shading pass or holds the next ray.  What changes is only when the block gives control
-// back: a lane whose traversal has finished is either SWAPPABLE (its S context holds a ray: one cheap swap step and it walks again)
-// or BLOCKED (S must be shaded first), and the two weigh differently:
-//   leave (return 0) when  swappable * w_swap + blocked * w_blocked  >  max(fringe * w_fringe, inner << 8);   1 = FRINGE visit wins
-// `alive` = lanes that still own work, `spend` = lanes whose S context is ready to take over (both wave masks, constant while the
-// block runs: S contexts only change in the service phase outside).
-__device__ __forceinline__ uint32_t inner_phase_duo_asm(Trav &tv, const NodeSrc &ns, V3 o, V3 inv, uint32_t n_inner, unsigned long long alive,
-                                                        unsigned long long spend, uint32_t w_swap, uint32_t w_blocked, uint32_t score_fringe) {
-    const f2 p0 = mk2(o.x, o.y), p1 = mk2(o.z, inv.x), p2 = mk2(inv.y, inv.z);
-    const int minus_stride = -kStackStride<true>, plus_stride = kStackStride<true>;
-    const uint32_t refs = (uint32_t)(uintptr_t)ns.lds_r0;
-    uint32_t kind;
-    asm volatile(
-        "s_mov_b64 s[80:81], exec\n\t"
-        ".Lsrt_duo_decide%=:\n\t"
-        "v_cmp_lt_i32 vcc, -1, %[node]\n\t"                          /* traversing */
-        "v_cmp_le_i32_e64 s[82:83], %[ninner], %[node]\n\t"          /* ... at a fringe record */
-        "s_bcnt1_i32_b64 s86, vcc\n\t"
-        "s_bcnt1_i32_b64 s87, s[82:83]\n\t"
-        "s_andn2_b64 s[84:85], %[alive], vcc\n\t"                    /* lanes with work but no ray under way */
-        "s_and_b64 s[90:91], s[84:85], %[spend]\n\t"                 /* ... that a swap step can serve */
-        "s_bcnt1_i32_b64 s88, s[84:85]\n\t"
-        "s_bcnt1_i32_b64 s89, s[90:91]\n\t"
-        "s_sub_u32 s88, s88, s89\n\t"                                /* blocked: need a shading pass first */
-        "s_mul_i32 s88, s88, %[wblk]\n\t"
-        "s_mul_i32 s89, s89, %[wswap]\n\t"
-        "s_add_u32 s88, s88, s89\n\t"
-        "s_sub_u32 s86, s86, s87\n\t"                                /* lanes at an inner record */
-        "s_mul_i32 s89, s87, %[wfringe]\n\t"
-        "s_lshl_b32 s84, s86, 8\n\t"
-        "s_max_u32 s85, s89, s84\n\t"
-        "s_mov_b32 %[kind], 0\n\t"
-        "s_cmp_gt_u32 s88, s85\n\t"
-        "s_cbranch_scc1 .Lsrt_duo_end%=\n\t"                         /* service phase (or nothing traversing) */
-        "s_cmp_eq_u32 s85, 0\n\t"
-        "s_cbranch_scc1 .Lsrt_duo_end%=\n\t"                         /* nothing traversing and nothing to serve: the caller decides */
-        "s_mov_b32 %[kind], 1\n\t"
-        "s_cmp_gt_u32 s89, s84\n\t"
-        "s_cbranch_scc1 .Lsrt_duo_end%=\n\t"                         /* FRINGE visit */
-        "s_add_u32 s87, s86, 2\n\t"                                  /* stay = ceil(inner lanes / 3) */
-        "s_mul_hi_u32 s87, s87, 0xaaaaaaab\n\t"
-        "s_lshr_b32 s87, s87, 1\n\t"
-        "s_andn2_b64 exec, vcc, s[82:83]\n\t"                        /* the lanes at inner records */
-        SRT_INNER_VISIT_ASM SRT_INNER_NEXT3_ASM
-        SRT_INNER_VISIT_ASM SRT_INNER_NEXT3_ASM
-        SRT_INNER_VISIT_ASM SRT_INNER_NEXT3_ASM
-        SRT_INNER_VISIT_ASM SRT_INNER_NEXT3_ASM
-        SRT_INNER_VISIT_ASM SRT_INNER_NEXT3_ASM
-        SRT_INNER_VISIT_ASM SRT_INNER_NEXT3_ASM
-        SRT_INNER_VISIT_ASM SRT_INNER_NEXT3_ASM
-        SRT_INNER_VISIT_ASM
-        ".Lsrt_duo_burst_end%=:\n\t"
-        "s_mov_b64 exec, s[80:81]\n\t"
-        "s_branch .Lsrt_duo_decide%=\n\t"
-        ".Lsrt_duo_end%=:\n\t"
-        : [node] "+v"(tv.node), [top] "+v"(tv.top), [sp] "+v"(tv.sp), [kind] "=&s"(kind)
-        : [nf0] "v"(tv.nf[0]), [nf1] "v"(tv.nf[1]), [nf2] "v"(tv.nf[2]), [p0] "v"(p0), [p1] "v"(p1), [p2] "v"(p2), [c] "v"(tv.c),
-          [ms] "v"(minus_stride), [ps] "v"(plus_stride), [ninner] "s"(n_inner), [refs] "s"(refs), [alive] "s"(alive), [spend] "s"(spend),
-          [wswap] "s"(w_swap), [wblk] "s"(w_blocked), [wfringe] "s"(score_fringe)
-        : "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114",
-          "v115", "v116", "v117", "v118", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "vcc",
           "scc", "memory");
     return kind;
 }

@@ -405,17 +405,6 @@ int flatten_scene(const srt_scene &s, FlatScene &out) {
         }
     }
     auto child_ref = [&](int32_t k) -> int32_t { return s.nodes[k].prim >= 0 ? ~s.nodes[k].prim : rec_index[k]; };
-    // A leaf's reference inside a FRINGE record also carries the CLASS of its triangle's material in bits 28-30 (triangle indices
-    // stay below 2^24): 0 lambertian / any type material::scatter sends to its default branch, 1 metallic, 2 dielectric, 3
-    // emissive.  The traversal hands the reference on as the hit word, so a kernel knows which shading pass a hit belongs to
-    // without loading anything (render_kernel_duo); index arithmetic uses 24-bit multiplies or masks the bits off.
-    auto leaf_class = [&](int32_t prim) -> uint32_t {
-        const uint32_t t = s.mats[s.raw[(size_t)prim].mat_index].material_type;
-        return t == SRT_MAT_METALLIC ? 1u : (t == SRT_MAT_DIELECTRIC ? 2u : (t == SRT_MAT_EMISSIVE ? 3u : 0u));
-    };
-    auto fringe_ref = [&](int32_t k) -> int32_t {
-        return s.nodes[k].prim >= 0 ? (int32_t)~((uint32_t)s.nodes[k].prim | (leaf_class(s.nodes[k].prim) << 28)) : rec_index[k];
-    };
     // INNER records, 64 B: three axis planes (lo_L, lo_R, hi_L, hi_R), then lref, rref (see NodeSrc in srt_device.h).
     // FRINGE records, 96 B = 12 (left, right) pairs: pair k holds word k of the left child's block and word k of the right
     // child's block side by side -- a 16-byte load delivers two register pairs that feed the packed arithmetic directly.
@@ -440,7 +429,7 @@ int flatten_scene(const srt_scene &s, FlatScene &out) {
         } else {
             float *o = &out.fringe[24 * (r - n_in)];
             const BvhNode *ch[2] = {&l, &rr};
-            const int32_t refs[2] = {fringe_ref(nd.left), fringe_ref(nd.right)};
+            const int32_t refs[2] = {child_ref(nd.left), child_ref(nd.right)};
             for (int k = 0; k < 2; k++) {
                 float b[12] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                 if (ch[k]->prim >= 0) {

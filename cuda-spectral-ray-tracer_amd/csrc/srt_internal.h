@@ -54,9 +54,6 @@ struct RenderParams {
     uint32_t waves_per_cu_override;       // 0 = occupancy API
     uint32_t score_shade, score_fringe;   // step-choice weights, 256 / relative step cost (both >= 1)
     uint32_t debug_lane_limit;            // experiments only (env SRT_DEBUG_LANE_LIMIT): lanes >= limit of every tile stay idle
-    // render_kernel_duo: weights of a lane that a swap step can serve / that is blocked until its other pixel is shaded (256 = a lane
-    // at an inner record), and the number of waiting lanes at which the shading pass of a class runs unprompted
-    uint32_t duo_w_swap, duo_w_blocked, duo_fill_d, duo_fill_g, duo_fill_e;
     // state / outputs
     uint32_t *rng;                        // SoA: 6 planes of n_lanes words, indexed by the block-linear idx
     uint32_t n_lanes;                     // tx*ty*bx*by
@@ -78,10 +75,6 @@ struct ScatterParams {
 
 hipError_t launch_init_rng(uint32_t *rng, uint32_t n_lanes, uint64_t seed, hipStream_t st);
 hipError_t launch_render(const RenderParams &p, uint32_t n_cu, int mode, hipStream_t st);   // mode 0 render, 1 instrumented, 2 cost probe
-constexpr int kDuoWavesPerBlock = 12;      // render_kernel_duo: one 768-thread workgroup per CU, 3 waves / SIMD at <= 168 VGPRs
-bool render_duo_eligible(int stack_depth, int n_records, int n_inner, int root_ref);
-size_t render_duo_lds_bytes(int stack_depth, int n_inner);
-hipError_t launch_render_duo(const RenderParams &p, uint32_t n_cu, hipStream_t st);
 hipError_t launch_order_tiles(const uint32_t *cost, uint32_t *sorted, uint32_t *rows, uint32_t n, uint32_t n_waves,
                               uint32_t split_load_pct, uint32_t *queue_info, uint32_t order_max_pct, uint32_t split_by_key, hipStream_t st);
 hipError_t launch_scatter(const ScatterParams &p, hipStream_t st);

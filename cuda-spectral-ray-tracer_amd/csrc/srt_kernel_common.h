@@ -1,5 +1,5 @@
-// srt_kernel_common.h -- pieces shared by the render kernels (srt_kernels.hip: render_kernel; srt_kernels_duo.hip: render_kernel_duo):
-// the LDS map of a workgroup, the block of launch uniforms kept in LDS, small wave-level helpers.
+// srt_kernel_common.h -- the LDS map of a render workgroup, the block of launch uniforms kept in LDS, compile-time knobs and small
+// wave-level helpers of srt_kernels.hip (kept apart so that kernel experiments in a second translation unit can share them).
 #pragma once
 #include "srt_device.h"
 #include "srt_internal.h"

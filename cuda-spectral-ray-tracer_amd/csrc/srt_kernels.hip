@@ -836,7 +836,7 @@ __global__ __launch_bounds__(64) void trace_rays_kernel(const RenderParams P, co
         else if (tv.node >= 0) trav_step_inner<false, false, false>(tv, ns, o, inv, my_stack, ts);   // n_cached = 0: global records
     }
     const float t = tv.c;
-    const int tri = tv.hit < 0 ? -1 : (tv.hit & 0x0fffffff);      // (bits 28-30 of a hit word: the material class, flatten_scene)
+    const int tri = tv.hit;
     if (active) {
         float ff = 0.f, mat = 0.f;
         if (tri >= 0) {

@@ -52,16 +52,6 @@ class Renderer:
         self._ck(B.lib().srt_launch_plan(self._h, C.byref(w), C.byref(n), C.byref(a), C.byref(r)))
         return dict(waves_per_cu=w.value, n_cached=n.value, all_cached=bool(a.value), narrow_refs=bool(r.value))
 
-    def set_kernel_variant(self, variant):
-        """0 auto, 1 render_kernel (one pixel per lane), 2 render_kernel_duo (two pixels per lane) whenever the scene qualifies"""
-        self._ck(B.lib().srt_set_kernel_variant(self._h, int(variant)))
-
-    def last_kernel_variant(self):
-        """what the last render_chunk launched: 0 render_kernel, 1 render_kernel_duo"""
-        v = C.c_int()
-        self._ck(B.lib().srt_last_kernel_variant(self._h, C.byref(v)))
-        return v.value
-
     def set_camera(self, cam):
         self._ck(B.lib().srt_set_camera(self._h, C.byref(cam)))
 
@@ -280,7 +270,7 @@ class Comm:
         return dict(rays=rays.value, paths=paths.value, max_kernel_ms=ms.value)
 
 
-def render_image(scene, cam, width, height, spp, bounce_limit, seed=1984, device=0, count_traversal=False, renderer=None, variant=None):
+def render_image(scene, cam, width, height, spp, bounce_limit, seed=1984, device=0, count_traversal=False, renderer=None):
     """Whole-image single-chunk render on one GPU (the reference's default configuration, Q13).
     Returns dict with block-linear planes, row-major quantised planes, stats and kernel ms."""
     r = renderer or Renderer(device)
@@ -289,16 +279,12 @@ def render_image(scene, cam, width, height, spp, bounce_limit, seed=1984, device
     r.init_device_params(width, height, spp, bounce_limit, seed)
     r.set_partition(0, 1)
     r.set_count_traversal(count_traversal)
-    if variant is not None:
-        r.set_kernel_variant(variant)
     planes_before = r.gather_planes
     r.set_gather_planes(9)            # the parity planes (unquantised sRGB, XYZ sums) are part of what this returns
     r.render_chunk(width, height, 0, 0)
     r.scatter_tiles()
-    if variant is not None:
-        r.set_kernel_variant(0)
     r.set_gather_planes(planes_before)
-    out = dict(variant=r.last_kernel_variant(), fb=r.read_fb(), lin=r.read_fb_aux(1), xyz=r.read_fb_aux(2), rowmajor=r.read_fb_rowmajor(width, height),
+    out = dict(fb=r.read_fb(), lin=r.read_fb_aux(1), xyz=r.read_fb_aux(2), rowmajor=r.read_fb_rowmajor(width, height),
                stats=r.stats(), kernel_ms=r.last_kernel_ms(), geom=dict(r.geom))
     if renderer is None:
         r.close()

@@ -191,13 +191,6 @@ SRT_API int srt_set_camera(srt_ctx *ctx, const srt_camera_data *cam);
  * records resident in LDS, whether that is the whole inner tree (kernel variant ALL_CACHED) and whether record references fit 15
  * bits (variant NARROW).  Any pointer may be NULL. */
 SRT_API int srt_launch_plan(const srt_ctx *ctx, int *waves_per_cu, int *n_cached, int *all_cached, int *narrow_refs);
-/* Two render kernels produce the same image: render_kernel (one pixel per lane: the shortest chain per pixel) and render_kernel_duo
- * (two pixels per lane, shading batched by material class: more rays per second when a launch has many tiles per wave).  variant
- * 0 (default) chooses per launch, 1 = always render_kernel, 2 = render_kernel_duo whenever the scene qualifies (inner tree LDS
- * resident, 15-bit record references).  Instrumented launches (srt_set_count_traversal) always use render_kernel.
- * srt_last_kernel_variant: what the last srt_render_chunk launched (0 render_kernel, 1 render_kernel_duo). */
-SRT_API int srt_set_kernel_variant(srt_ctx *ctx, int variant);
-SRT_API int srt_last_kernel_variant(const srt_ctx *ctx, int *variant);
 /* Dynamic LDS bytes of one workgroup of that launch (tables + inner-record cache + traversal stacks): the counterpart of the
  * reference's shared_mem_size (rendering/rendering.cu:290-301), which its run log reports as "shared memory byte size" (:342). */
 SRT_API int srt_launch_lds_bytes(const srt_ctx *ctx, size_t *bytes);

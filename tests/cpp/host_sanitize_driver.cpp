@@ -33,7 +33,7 @@ static int exercise(srt_scene *s, int mode, size_t expect_tris) {
     for (int k = 0; k < f.n_inner; k++)
         for (int c = 0; c < 2; c++) { int32_t ref; memcpy(&ref, &f.nodes[16 * k + 12 + c], 4); CHECK(ref >= 0 && ref < f.n_records); }
     for (int k = 0; k < f.n_records - f.n_inner; k++)
-        for (int c = 0; c < 2; c++) { int32_t ref; memcpy(&ref, &f.fringe[24 * k + 22 + c], 4); CHECK(ref < f.n_records && (ref >= 0 || (((size_t)(uint32_t)~ref & 0x0fffffffu) < n && ((uint32_t)~ref >> 28) <= 3u))); }      // (leaf: ~(triangle | class << 28))
+        for (int c = 0; c < 2; c++) { int32_t ref; memcpy(&ref, &f.fringe[24 * k + 22 + c], 4); CHECK(ref < f.n_records && (ref >= 0 || (size_t)~ref < n)); }
     const float eye[3] = {-3.f, 7.f, 21.f};
     CHECK(srt_scene_order_children(s, eye) == SRT_OK);
     srt::FlatScene g;

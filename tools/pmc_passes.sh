@@ -1,6 +1,6 @@
 #!/bin/bash
 # PMC passes for the render kernel (run on the GPU box through gpurun).  KERNEL_FILTER (default "render_kernel<0") selects the
-# dispatches that are summed, e.g. KERNEL_FILTER=render_kernel_duo.  Each --pmc set is its own run, with
+# dispatches that are summed, e.g. KERNEL_FILTER=init_rng_kernel.  Each --pmc set is its own run, with
 # --kernel-trace only (no other trace domains), as MI355X_MICROARCH.md prescribes.  Usage: tools/pmc_passes.sh <outdir> [bench args]
 set -u
 OUT=${1:-gpurun_out/pmc}; shift || true
