@@ -59,8 +59,12 @@ struct srt_ctx {
     uint32_t debug_lane_limit = 0;                     // env SRT_DEBUG_LANE_LIMIT (experiments: partial tiles)
     uint32_t split_load_pct = 200;                    // env SRT_SPLIT_LOAD: load factor (%) of the capacity constraint in order_tiles_kernel's split policy (0 = never split)
     uint32_t probe_spp = 2;                            // samples of the cost probe (env SRT_PROBE_SPP, 0 = no ordering)
-    uint32_t split_by_key = 0;                         // split policy: latency from the sort key instead of the tile cost (env SRT_SPLIT_BY_KEY)
-    uint32_t order_max_pct = 0;                        // queue order: tile cost moved this % towards 64 x its most expensive pixel (env SRT_ORDER_MAX_PCT)
+    // queue order: tile cost moved this % towards 64 x its most expensive pixel (order_tiles_kernel).  -1 = automatic: 100 when the
+    // inner tree is partly served by L2 AND the launch has fewer than 8 tiles per persistent wave (a rank's share of a multi-GPU frame:
+    // every step of such a chain is an L2 round trip, and a long pixel inside an average tile ends the launch late: cfg 5 at W = 8
+    // 2331 -> 2245 ms), else 0 (measured worse on LDS-resident trees: cfg 3 at W = 2 187 -> 196 ms, cfg 2 44.8 -> 45.4 ms).
+    // env SRT_ORDER_MAX_PCT
+    int order_max_pct = -1;
     uint32_t *d_tile_cost = nullptr, *d_tile_order = nullptr;
     size_t tile_sched_capacity = 0;
     uint64_t lanes_allocated = 0;                       // size of d_rng / d_fb in lanes
@@ -166,8 +170,7 @@ int srt_create(int device, srt_ctx **out) {
     if (const char *ev = getenv("SRT_SCORE_FRINGE")) c->score_fringe = (uint32_t)std::max(1, atoi(ev));   // 0 would starve fringe lanes
     if (const char *ev = getenv("SRT_DEBUG_LANE_LIMIT")) c->debug_lane_limit = (uint32_t)std::max(0, atoi(ev));
     if (const char *ev = getenv("SRT_SPLIT_LOAD")) c->split_load_pct = (uint32_t)std::max(0, atoi(ev));
-    if (const char *ev = getenv("SRT_SPLIT_BY_KEY")) c->split_by_key = atoi(ev) ? 1u : 0u;
-    if (const char *ev = getenv("SRT_ORDER_MAX_PCT")) c->order_max_pct = (uint32_t)std::min(400, std::max(0, atoi(ev)));
+    if (const char *ev = getenv("SRT_ORDER_MAX_PCT")) c->order_max_pct = std::min(400, std::max(-1, atoi(ev)));
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->n_cu = prop.multiProcessorCount;
@@ -377,7 +380,9 @@ int srt_render_chunk(srt_ctx *c, uint32_t width, uint32_t height, uint32_t offx,
         RoctxRange range_probe("srt cost probe + pixel queue");
         HIP_TRY(c, launch_render(pp, (uint32_t)c->n_cu, 2, st));
         const uint32_t split_pct = c->split_load_pct;
-        HIP_TRY(c, launch_order_tiles(c->d_tile_cost, sorted, rows, c->tiles_local, (uint32_t)c->n_cu * (uint32_t)plan.waves_per_cu, split_pct, queue_info, c->order_max_pct, c->split_by_key, st));   // device-side, no host sync
+        const uint32_t n_waves_plan = (uint32_t)c->n_cu * (uint32_t)plan.waves_per_cu;
+        const uint32_t order_pct = c->order_max_pct >= 0 ? (uint32_t)c->order_max_pct : ((!plan.all_cached && (uint64_t)c->tiles_local < 8ull * n_waves_plan) ? 100u : 0u);
+        HIP_TRY(c, launch_order_tiles(c->d_tile_cost, sorted, rows, c->tiles_local, (uint32_t)c->n_cu * (uint32_t)plan.waves_per_cu, split_pct, queue_info, order_pct, st));   // device-side, no host sync
         HIP_TRY(c, hipMemsetAsync(c->d_counters + kCounters, 0, sizeof(unsigned long long), st));   // rewind the queue head
         p.tile_order = rows;
         p.queue_rows = queue_info;

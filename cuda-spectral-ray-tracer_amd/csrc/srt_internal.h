@@ -76,7 +76,7 @@ struct ScatterParams {
 hipError_t launch_init_rng(uint32_t *rng, uint32_t n_lanes, uint64_t seed, hipStream_t st);
 hipError_t launch_render(const RenderParams &p, uint32_t n_cu, int mode, hipStream_t st);   // mode 0 render, 1 instrumented, 2 cost probe
 hipError_t launch_order_tiles(const uint32_t *cost, uint32_t *sorted, uint32_t *rows, uint32_t n, uint32_t n_waves,
-                              uint32_t split_load_pct, uint32_t *queue_info, uint32_t order_max_pct, uint32_t split_by_key, hipStream_t st);
+                              uint32_t split_load_pct, uint32_t *queue_info, uint32_t order_max_pct, hipStream_t st);
 hipError_t launch_scatter(const ScatterParams &p, hipStream_t st);
 hipError_t launch_unswizzle(const float *const src[3], float *const dst[3], uint32_t tx, uint32_t ty, uint32_t bx, uint32_t by,
                             uint32_t n_cols, uint32_t n_rows, uint32_t offx, uint32_t offy, uint32_t image_width,

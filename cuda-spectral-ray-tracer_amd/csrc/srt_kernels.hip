@@ -78,6 +78,19 @@ void render_launch_plan(int stack_depth, int n_records, int n_inner, LaunchPlan 
     lp.waves_per_cu = lp.waves_per_block * lp.blocks_per_cu;
 }
 
+// Cost band (0 = most expensive) of the first queue row that wave w of a workgroup takes (render_kernel S3): row = band * number of
+// workgroups + workgroup.  SRT_ASSIGN_PERM picks how the bands are dealt to the waves of a workgroup: 0 in wave order, 1 transposed
+// (w % 4) * 4 + w / 4, 2 boustrophedon over groups of four (0 1 2 3 | 7 6 5 4 | 8 ...), so that the four waves w, w + 4, w + 8, w + 12
+// -- one SIMD's, if waves go to SIMDs round robin -- hold bands of equal total rank.
+#ifndef SRT_ASSIGN_PERM
+#define SRT_ASSIGN_PERM 0
+#endif
+__device__ __forceinline__ uint32_t assigned_band(uint32_t w) {
+    if (SRT_ASSIGN_PERM == 1) return (w & 3u) * 4u + (w >> 2);
+    if (SRT_ASSIGN_PERM == 2) return (w & 4u) ? ((w & ~3u) | (3u - (w & 3u))) : w;
+    return w;
+}
+
 // init_random_states (rendering.cu:120-138): curand_init(seed + idx, 0, 0)
 __global__ void init_rng_kernel(uint32_t *rng, uint32_t n_lanes, uint64_t seed) {
     uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -394,7 +407,7 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
                     const bool assigned = SRT_ASSIGN_FIRST_ROW != 0 && m == ~0ull && ((U->first_row_taken >> wave) & 1u) == 0u;
                     if (assigned) {      // (the per-wave "taken" bit lives in LDS: nothing stays live in the persistent loop for it)
                         if (lane == 0) atomicOr((unsigned int *)&U->first_row_taken, 1u << wave);
-                        base = (wave * gridDim.x + blockIdx.x) * 64u;
+                        base = (assigned_band(wave) * gridDim.x + blockIdx.x) * 64u;
                     }
                     else {
                         if ((int)lane == leader) base = atomicAdd(join_ptr<uint32_t>(U->pixel_counter[0], U->pixel_counter[1]), (uint32_t)__popcll(m));
@@ -669,7 +682,7 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
 //    queue row = tile | part << 22 | s << 28;  queue_info[0] = number of rows.
 __global__ __launch_bounds__(1024) void order_tiles_kernel(const uint32_t *__restrict__ cost, uint32_t *__restrict__ sorted,
                                                           uint32_t *__restrict__ rows, uint32_t n, uint32_t n_waves,
-                                                          uint32_t split_load_pct, uint32_t *__restrict__ queue_info, uint32_t order_max_pct, uint32_t split_by_key) {
+                                                          uint32_t split_load_pct, uint32_t *__restrict__ queue_info, uint32_t order_max_pct) {
     constexpr uint32_t kBinsN = 4096;
     __shared__ uint32_t s_bin[kBinsN];
     __shared__ uint32_t s_max;
@@ -728,14 +741,15 @@ __global__ __launch_bounds__(1024) void order_tiles_kernel(const uint32_t *__res
     // latency with wave-slot time (a tile cut into 64 single-pixel rows costs 28x its unsplit slot time), so (b) is what
     // keeps a throughput-bound launch from splitting anything.  Bisection; every step is one parallel reduction.
     // (also keeps 64 * rows far below 2^32: the queue head is a 32-bit pixel-slot counter)
-    // latency estimate of a tile for the split policy: its cost, or (split_by_key) the sort key -- which weighs the tile's longest
-    // single chain: a tile of average cost that holds one very long pixel is as late as a tile of 64 such pixels
-    auto lat_of = [&](uint32_t k) -> uint32_t { return split_by_key ? key_of(k) : cost[k]; };
+    // (latency estimate of a tile for the split policy: its cost.  Using the sort key instead -- a tile of average cost that holds
+    // one very long pixel counted like 64 such pixels -- was measured and lost everywhere: cfg 3 at W = 4 / 8 125 -> 141 / 106 ->
+    // 135 ms, cfg 5 at W = 8 2245 -> 2262 ms; profiles/r04/cfg5_w8_tail.txt)
+    auto lat_of = [&](uint32_t k) -> uint32_t { return cost[k]; };
     const bool may_split = split_load_pct != 0u && n <= (1u << 20);
     float target = 3.0e38f;
     if (may_split) {
         const float load_factor = (float)split_load_pct * 0.01f;
-        const float lat_max = (float)(split_by_key ? s_kmax : s_max);
+        const float lat_max = (float)s_max;
         float lo_t = lat_max * g[6], hi_t = fmaxf(lat_max, load_factor * (float)s_sum / (float)(n_waves ? n_waves : 1u));
         for (int it = 0; it < 14; it++) {
             const float mid = 0.5f * (lo_t + hi_t);
@@ -943,9 +957,9 @@ hipError_t launch_render(const RenderParams &p, uint32_t n_cu, int mode, hipStre
 }
 
 hipError_t launch_order_tiles(const uint32_t *cost, uint32_t *sorted, uint32_t *rows, uint32_t n, uint32_t n_waves,
-                              uint32_t split_load_pct, uint32_t *queue_info, uint32_t order_max_pct, uint32_t split_by_key, hipStream_t st) {
+                              uint32_t split_load_pct, uint32_t *queue_info, uint32_t order_max_pct, hipStream_t st) {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(order_tiles_kernel, dim3(1), dim3(1024), 0, st, cost, sorted, rows, n, n_waves, split_load_pct, queue_info, order_max_pct, split_by_key);
+    hipLaunchKernelGGL(order_tiles_kernel, dim3(1), dim3(1024), 0, st, cost, sorted, rows, n, n_waves, split_load_pct, queue_info, order_max_pct);
     return hipGetLastError();
 }
 

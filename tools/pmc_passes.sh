@@ -4,7 +4,7 @@
 # --kernel-trace only (no other trace domains), as MI355X_MICROARCH.md prescribes.  Usage: tools/pmc_passes.sh <outdir> [bench args]
 set -u
 OUT=${1:-gpurun_out/pmc}; shift || true
-ARGS=${@:---spp 64 --steps 1 --warmup 0 --no-cpu-baseline}
+ARGS=${@:---spp 64 --steps 1 --warmup 0 --no-cpu-baseline --no-calibration --no-other-configs --cfg5-spp 0}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p "$OUT"
 i=0
