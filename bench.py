@@ -32,8 +32,9 @@ the rate at which the chip issues wave64 vector instructions.  Two peaks are rep
              (MI355X_MICROARCH.md: one wave64 VALU instruction per 2 cycles per SIMD).
 achieved = useful VALU lane-ops per ray (active lanes summed over every vector instruction: SQ_THREAD_CYCLES_VALU / rays
 from a committed rocprofv3 --pmc pass, profiles/rNN/lane_ops_per_ray.json -- IMPORTED, labelled so, and tied to the kernel
-binary by a hash of its ISA listing: a mismatch is reported as "achieved_source": "STALE ...") x rays per launch (live) /
-render-kernel time (live, HIP events on the launch stream).
+binary by the sha256 of the kernel's machine code in the gfx950 code object of the library that is loaded (tools/kernel_id.py): a
+mismatch is reported as "achieved_source": "STALE ...") x rays per launch (live) / render-kernel time (live, HIP events on the
+launch stream).
 
 `cpu_baseline` is the CPU oracle (a port: the reference has no CPU path) timed on this box's USABLE host cores
 (scheduler affinity and cgroup quota, not os.cpu_count()) on a bounded sample of the same workload, its one-thread rate

@@ -770,6 +770,8 @@ __global__ __launch_bounds__(1024) void order_tiles_kernel(const uint32_t *__res
     const uint32_t per = (n + 1023u) / 1024u;
     const uint32_t lo = min(n, t * per), hi = min(n, lo + per);
     uint32_t mine = 0;
+    // (queue position q holds sorted[q].  Sending the head of the order -- the longest chains -- to the END of the queue, so that they run
+    // when the machine has emptied, was measured on cfg 5 at W = 8 and costs 0.5 s and more: profiles/r04/cfg5_w8_tail.txt)
     for (uint32_t k = lo; k < hi; k++) mine += 1u << level_of(sorted[k]);
     s_scan[t] = mine;
     __syncthreads();
