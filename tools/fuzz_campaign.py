@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""A longer run of the GPU suite's random-scene fuzz (tests/test_gpu_parity.py::test_random_scenes_fuzz: triangle soups with shared
+vertices / lattice coincidences / axis-aligned triangles, random materials incl. dielectric with quirk Q1 and emissive, both BVH
+builders, lens on / off, depth 1..16): GPU (both kernel builds) == oracle bit for bit, work counters included.  The oracle is the
+checker here, as in the tests.  usage: tools/fuzz_campaign.py [first seed] [count]"""
+import importlib, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+srt = importlib.import_module("cuda-spectral-ray-tracer_amd")
+import oracle_binding as orc
+from helpers import oracle_scene_for, bits
+import test_gpu_parity as T
+
+first = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+count = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+gpu = srt.Renderer(0); gpu.set_gather_planes(9)
+bad = 0
+for seed in range(first, first + count):
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.integers(3, 400))
+    tris, mats = [], []
+    n_mats = int(rng.integers(1, 14))
+    for k in range(n_mats):
+        mtype = int(rng.choice([0, 0, 0, 1, 1, 2, 2, 4, 6, 17]))
+        grey = float(rng.choice([0.0, 0.3, 0.5, 0.73, 1.0]))
+        mats.append((mtype, (grey, grey, grey), float(rng.uniform(0, 0.6)), float(rng.uniform(0.5, 3.0))))
+    verts = rng.uniform(-5, 5, (max(4, n // 2), 3)).astype(np.float32)
+    lattice = rng.random(verts.shape[0]) < 0.3
+    verts[lattice] = np.round(verts[lattice])
+    for k in range(n):
+        if rng.random() < 0.6:
+            i0, i1, i2 = rng.choice(verts.shape[0], 3, replace=False)
+            v0, v1, v2 = verts[i0], verts[i1], verts[i2]
+        else:
+            c = rng.uniform(-5, 5, 3)
+            v0, v1, v2 = (c + rng.normal(0, rng.choice([0.01, 0.5, 2.0]), 3) for _ in range(3))
+        if rng.random() < 0.15:
+            ax = int(rng.integers(0, 3)); v0 = np.array(v0); v1 = np.array(v1); v2 = np.array(v2)
+            v1[ax] = v0[ax]; v2[ax] = v0[ax]
+        tris.append((tuple(float(x) for x in v0), tuple(float(x) for x in v1), tuple(float(x) for x in v2), int(rng.integers(0, n_mats)), int(rng.choice([0, 0, 1, 2, 3]))))
+    bg = float(rng.choice([0.5, 1.0, 0.5, 0.0]))
+    mode = int(rng.integers(0, 2))
+    scene = T._custom_scene(srt, tris, mats, (bg, bg, bg)).build_bvh(mode, 1984)
+    W, H, spp, depth = int(rng.integers(9, 90)), int(rng.integers(9, 60)), int(rng.integers(1, 12)), int(rng.integers(1, 17))
+    cam = srt.camera_init(W, H, float(rng.uniform(20, 90)), tuple(rng.uniform(-12, 12, 3)), tuple(rng.uniform(-2, 2, 3)),
+                          defocus_angle=float(rng.choice([0.0, 0.0, 1.5])), focus_dist=float(rng.uniform(5, 15)))
+    ref = oracle_scene_for(orc, scene, mode).render(cam, W, H, spp, depth)
+    for counted in (True, False):
+        out = srt.render_image(scene, cam, W, H, spp, depth, renderer=gpu, count_traversal=counted)
+        ok = all(np.array_equal(bits(a), bits(b)) for a, b in zip(out["xyz"], ref["xyz"])) and all(np.array_equal(a, b) for a, b in zip(out["fb"], ref["fb"]))
+        ok = ok and out["stats"]["rays"] == ref["stats"]["rays"]
+        if counted:
+            n_nan = out["stats"]["util"][2]
+            ok = ok and out["stats"]["node_visits"] + n_nan * (n - 1) == ref["stats"]["trav_iters"] and out["stats"]["tri_tests"] + n_nan * n == ref["stats"]["tri_tests"]
+        if not ok:
+            bad += 1
+            print("MISMATCH seed %d counted=%s (%d tris, %d mats, mode %d, %dx%d %d spp depth %d)" % (seed, counted, n, n_mats, mode, W, H, spp, depth), flush=True)
+    if (seed - first) % 25 == 24:
+        print("seed %d done, %d mismatches so far" % (seed, bad), flush=True)
+print("fuzz campaign: seeds %d..%d, both kernel builds, %d mismatches" % (first, first + count - 1, bad))
+sys.exit(1 if bad else 0)
