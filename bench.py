@@ -627,9 +627,16 @@ def small_roofline(renderer, scene_id, rays_per_launch, kms, lib_path):
 def secondary_workload(srt, job, scene_id, bvh, W, H, spp, depth, with_roofline=True):
     """one frame of another BASELINE configuration on the same ranks, outside the headline's timed region"""
     t_build = time.time()
-    scene = srt.Scene.builtin(scene_id, 0).build_bvh(bvh, 1984)
-    cam = scene.default_camera(W, H)
-    job.upload(scene, cam)
+    ok, err = 1.0, None
+    try:
+        scene = srt.Scene.builtin(scene_id, 0).build_bvh(bvh, 1984)
+        cam = scene.default_camera(W, H)
+        job.upload(scene, cam)
+    except Exception as e:      # noqa: BLE001
+        ok, err = 0.0, e
+    # every rank or none enters the collectives below: a rank that could not set the workload up must not leave the others waiting
+    if min(job.reduce_max([-ok])) > -0.5 or ok < 0.5:
+        raise RuntimeError("secondary workload not set up on every rank (this rank: %r)" % (err,))
     t_build = time.time() - t_build
     tc = traversal_counts(job, W, H, depth)
     tf = timed_frames(job, W, H, spp, depth, 1, 0, label="[%s %dx%d %d spp] " % (SCENE_NAMES.get(scene_id, scene_id), W, H, spp))
