@@ -827,6 +827,10 @@ def main():
     if out is not None and not args.no_cpu_baseline and job.world == 1:
         try:
             out["cpu_baseline"] = cpu_baseline(srt, scene, cam, W, H, args.depth, args.bvh, gpu_renderer=job.root)
+            # the extrapolated wall time of ONE frame of this workload on those host cores (the rate is spp independent)
+            if out["cpu_baseline"].get("value"):
+                out["cpu_baseline"]["extrapolated_wall_s_per_frame"] = (total_rays / max(args.steps, 1)) / (out["cpu_baseline"]["value"] * 1e6)
+                out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         except Exception as e:   # noqa: BLE001 -- the checker is optional for the measurement itself
             out["cpu_baseline"] = {"value": None, "unit": "Mray/s", "cores": usable_cores()[0], "kind": "port", "sample": "failed: %r" % (e,)}
         try:
