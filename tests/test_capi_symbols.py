@@ -70,3 +70,26 @@ def test_missing_rccl_is_reported_not_fatal(srt):
     env = dict(os.environ, SRT_RCCL_LIB="/no-such-dir/librccl.so.1")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
+
+
+def test_kernel_identity_from_the_code_object(srt):
+    """tools/kernel_id.py finds the production render kernels inside the gfx950 code object of the built library (offload bundle in
+    .hip_fatbin -> ELF symbol table -> the kernel's bytes) -- what bench.py ties an imported PMC figure to.  No GPU needed."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("kernel_id", os.path.join(ROOT, "tools", "kernel_id.py"))
+    kid = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kid)
+    hs = kid.code_hashes(srt.binding.LIB_PATH)
+    assert set(hs) == {(0, 0), (0, 1), (1, 0), (1, 1)}                      # render_kernel<0, NARROW, ALL_CACHED>
+    assert all(len(v) == 64 and int(v, 16) >= 0 for v in hs.values()) and len(set(hs.values())) == 4
+    h, note = kid.code_hash(srt.binding.LIB_PATH, 1, 1)
+    assert h == hs[(1, 1)] and "machine code" in note
+    assert kid.code_hash("/no/such/library.so", 1, 1)[0] is None
+    # the committed PMC entries name the kernel they were taken on; say (do not require) whether this build is that kernel
+    f = os.path.join(ROOT, "profiles", "r04", "lane_ops_per_ray.json")
+    if os.path.exists(f):
+        doc = json.load(open(f))
+        for scene, variant in (("scene_100", (1, 1)), ("scene_101", (0, 0)), ("scene_1", (1, 1))):
+            assert len(doc[scene]["kernel_code_sha256"]) == 64
+            print("%s: PMC pass %s this build's render_kernel<0,%d,%d>" % (scene, "==" if doc[scene]["kernel_code_sha256"] == hs[variant] else "!=", *variant))
