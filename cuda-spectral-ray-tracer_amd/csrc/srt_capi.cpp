@@ -60,9 +60,10 @@ struct srt_ctx {
     uint32_t split_load_pct = 200;                    // env SRT_SPLIT_LOAD: load factor (%) of the capacity constraint in order_tiles_kernel's split policy (0 = never split)
     uint32_t probe_spp = 2;                            // samples of the cost probe (env SRT_PROBE_SPP, 0 = no ordering)
     // queue order: tile cost moved this % towards 64 x its most expensive pixel (order_tiles_kernel).  -1 = automatic: 100 when the
-    // inner tree is partly served by L2 AND the launch has fewer than 8 tiles per persistent wave (a rank's share of a multi-GPU frame:
+    // inner tree is partly served by L2 AND the launch has fewer than 6 tiles per persistent wave (a rank's share of an 8-GPU frame:
     // every step of such a chain is an L2 round trip, and a long pixel inside an average tile ends the launch late: cfg 5 at W = 8
-    // 2331 -> 2245 ms), else 0 (measured worse on LDS-resident trees: cfg 3 at W = 2 187 -> 196 ms, cfg 2 44.8 -> 45.4 ms).
+    // 2331 -> 2245 ms; with 8 tiles per wave -- cfg 5 at W = 4 -- it already loses: 3665 -> 3812 ms), else 0 (measured worse on LDS-resident
+    // trees: cfg 3 at W = 2 187 -> 196 ms, cfg 2 44.8 -> 45.4 ms).
     // env SRT_ORDER_MAX_PCT
     int order_max_pct = -1;
     uint32_t *d_tile_cost = nullptr, *d_tile_order = nullptr;
@@ -381,7 +382,7 @@ int srt_render_chunk(srt_ctx *c, uint32_t width, uint32_t height, uint32_t offx,
         HIP_TRY(c, launch_render(pp, (uint32_t)c->n_cu, 2, st));
         const uint32_t split_pct = c->split_load_pct;
         const uint32_t n_waves_plan = (uint32_t)c->n_cu * (uint32_t)plan.waves_per_cu;
-        const uint32_t order_pct = c->order_max_pct >= 0 ? (uint32_t)c->order_max_pct : ((!plan.all_cached && (uint64_t)c->tiles_local < 8ull * n_waves_plan) ? 100u : 0u);
+        const uint32_t order_pct = c->order_max_pct >= 0 ? (uint32_t)c->order_max_pct : ((!plan.all_cached && (uint64_t)c->tiles_local < 6ull * n_waves_plan) ? 100u : 0u);
         HIP_TRY(c, launch_order_tiles(c->d_tile_cost, sorted, rows, c->tiles_local, (uint32_t)c->n_cu * (uint32_t)plan.waves_per_cu, split_pct, queue_info, order_pct, st));   // device-side, no host sync
         HIP_TRY(c, hipMemsetAsync(c->d_counters + kCounters, 0, sizeof(unsigned long long), st));   // rewind the queue head
         p.tile_order = rows;
