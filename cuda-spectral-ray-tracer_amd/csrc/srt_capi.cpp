@@ -510,7 +510,8 @@ int srt_read_fb_rowmajor(srt_ctx *c, float *r, float *g, float *b, uint32_t imag
 }
 
 int srt_get_tile_costs(srt_ctx *c, uint32_t *out, size_t n) {
-    if (!c || !out || !c->d_tile_cost || n > c->tile_sched_capacity) return fail(c, SRT_ERR_INVALID, "srt_get_tile_costs: no probe has run / bad size");
+    // n = tiles_local: the probe's cost per local tile; n = 2 * tiles_local: followed by the cost of each tile's most expensive pixel
+    if (!c || !out || !c->d_tile_cost || (n > c->tiles_local && n != 2 * (size_t)c->tiles_local)) return fail(c, SRT_ERR_INVALID, "srt_get_tile_costs: no probe has run / bad size");
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipDeviceSynchronize());
     HIP_TRY(c, hipMemcpy(out, c->d_tile_cost, n * sizeof(uint32_t), hipMemcpyDeviceToHost));

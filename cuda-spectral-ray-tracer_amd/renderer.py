@@ -113,11 +113,12 @@ class Renderer:
         self._ck(B.lib().srt_read_fb_rowmajor(self._h, B.fptr(r), B.fptr(g), B.fptr(b), image_width, image_height))
         return r, g, b
 
-    def tile_costs(self):
+    def tile_costs(self, with_max_pixel=False):
+        """the cost probe's node visits per local tile; with_max_pixel: (per tile, of each tile's most expensive pixel)"""
         _, _, tl, _ = self.tile_buffer()
-        out = np.zeros(tl, np.uint32)
-        self._ck(B.lib().srt_get_tile_costs(self._h, out.ctypes.data_as(C.POINTER(C.c_uint32)), tl))
-        return out
+        out = np.zeros(tl * (2 if with_max_pixel else 1), np.uint32)
+        self._ck(B.lib().srt_get_tile_costs(self._h, out.ctypes.data_as(C.POINTER(C.c_uint32)), out.size))
+        return (out[:tl], out[tl:]) if with_max_pixel else out
 
     def stats(self):
         st = B.Stats()

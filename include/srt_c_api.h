@@ -238,7 +238,8 @@ SRT_API int srt_read_fb_rowmajor(srt_ctx *ctx, float *r, float *g, float *b, uin
  * when the last scatter did not write them (multi-GPU frame with the default 3-plane exchange unit). */
 SRT_API int srt_read_fb_aux(srt_ctx *ctx, int which, float *p0, float *p1, float *p2);
 
-/* Scheduling introspection: per-local-tile traversal cost measured by the probe of the last ordered launch (n = tiles_local). */
+/* Scheduling introspection: per-local-tile traversal cost measured by the probe of the last ordered launch (n = tiles_local; n = 2 *
+ * tiles_local: followed by the cost of every tile's most expensive pixel -- one pixel is one sequential chain). */
 SRT_API int srt_get_tile_costs(srt_ctx *ctx, uint32_t *out, size_t n);
 SRT_API int srt_get_stats(srt_ctx *ctx, srt_stats *out);       /* counters of the last srt_render_chunk */
 SRT_API int srt_set_count_traversal(srt_ctx *ctx, int on);     /* 1: instrumented kernel also counts V / T */
