@@ -947,6 +947,9 @@ template <int MODE, bool NARROW>
 static hipError_t launch_render_mode(const RenderParams &p, uint32_t n_cu, hipStream_t st) {
     LaunchPlan lp;
     render_launch_plan(p.stack_depth, p.n_records, p.n_inner, lp);
+    // (the ALL_CACHED variant reads packed 96-byte FRINGE records by a literal stride: never pick it for a scene that was uploaded
+    // with padded records -- the plan can only differ from the upload's when SRT_LDS_CACHE_MAX changed in between)
+    if (lp.all_cached && p.fringe_stride != 96u) lp.all_cached = false;
     return lp.all_cached ? launch_render_cached<MODE, NARROW, true>(p, lp, n_cu, st) : launch_render_cached<MODE, NARROW, false>(p, lp, n_cu, st);
 }
 

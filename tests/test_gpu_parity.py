@@ -739,6 +739,66 @@ def test_custom_scenes_edge_cases(srt, gpu, orc, case, count_traversal):
         assert max(float(p.max()) for p in out["xyz"]) > 0       # the camera sees something
 
 
+def _soup(srt, seed, n, spread=6.0, size=0.25):
+    """n small random triangles in a box, 6 materials (lambertian, metallic, dielectric, emissive), sky background"""
+    rng = np.random.default_rng(4000 + seed)
+    c = rng.uniform(-spread, spread, (n, 3))
+    v = [c + rng.normal(0, size, (n, 3)) for _ in range(3)]
+    v = [a.astype(np.float32).astype(np.float64) for a in v]
+    mat = rng.integers(0, 6, n)
+    tris = [(tuple(v[0][k]), tuple(v[1][k]), tuple(v[2][k]), int(mat[k]), 0) for k in range(n)]
+    mats = [(0, (0.5, 0.5, 0.5), 0.0, 0.0), (0, (0.73, 0.73, 0.73), 0.0, 0.0), (1, (1.0, 1.0, 1.0), 0.2, 0.0), (2, (1.0, 1.0, 1.0), 0.0, 0.0),
+            (4, (1.0, 1.0, 1.0), 0.0, 2.0), (1, (0.5, 0.5, 0.5), 0.0, 0.0)]
+    return _custom_scene(srt, tris, mats, (0.5, 0.5, 0.5))
+
+
+def _assert_render_matches(out, ref, what, count_traversal, n_tris):
+    assert_planes_equal(out["xyz"], ref["xyz"], what + " XYZ")
+    assert_planes_equal(out["lin"], ref["lin"], what + " unquantised sRGB")
+    assert_planes_equal(out["fb"], ref["fb"], what + " fb")
+    st, rs = out["stats"], ref["stats"]
+    assert st["rays"] == rs["rays"] and st["paths"] == rs["paths"]
+    if count_traversal:
+        n_nan = st["util"][2]
+        assert st["node_visits"] + n_nan * (n_tris - 1) == rs["trav_iters"] and st["tri_tests"] + n_nan * n_tris == rs["tri_tests"]
+
+
+@pytest.mark.parametrize("count_traversal", VARIANTS)
+@pytest.mark.parametrize("cap", [0, 3])
+@pytest.mark.parametrize("sid,mode,W,H,spp,depth", [SCENES[0], SCENES[2], SCENES[3], SCENES[4], SCENES[9], SCENES[11]])
+def test_partly_cached_narrow_tree_forced_on_small_scenes(srt, gpu, orc, monkeypatch, sid, mode, W, H, spp, depth, cap, count_traversal):
+    """render_kernel<MODE, NARROW = true, ALL_CACHED = false>: 16-bit child references, inner records beyond an LDS prefix served by
+    L2 -- the variant mid-size scenes (about 5 k to 60 k triangles) launch, which neither the small test scenes (whole tree in LDS)
+    nor cfg 5's mesh (32-bit references) reach.  Forced here on the small scenes by capping the LDS cache at `cap` records
+    (SRT_LDS_CACHE_MAX, read with every launch plan; 0 = every inner record comes from L2), both kernel builds."""
+    monkeypatch.setenv("SRT_LDS_CACHE_MAX", str(cap))
+    scene = srt.Scene.builtin(sid, 0).build_bvh(mode, 1984)
+    cam = scene.default_camera(W, H)
+    out = srt.render_image(scene, cam, W, H, spp, depth, renderer=gpu, count_traversal=count_traversal)
+    plan = gpu.launch_plan()
+    assert plan["narrow_refs"] and not plan["all_cached"] and plan["n_cached"] <= cap
+    ref = oracle_scene_for(orc, scene, mode).render(cam, W, H, spp, depth)
+    _assert_render_matches(out, ref, "scene %d cap %d" % (sid, cap), count_traversal, scene.n_tris)
+    monkeypatch.delenv("SRT_LDS_CACHE_MAX")
+    gpu.upload_scene(scene)      # (leave the session's context with a plan that matches its upload)
+
+
+@pytest.mark.parametrize("count_traversal", VARIANTS)
+@pytest.mark.parametrize("n,mode", [(9000, 1), (14000, 0), (30000, 1)])
+def test_mid_size_scenes_bit_exact(srt, gpu, orc, n, mode, count_traversal):
+    """The same variant reached the natural way: soups of 9 000 / 14 000 / 30 000 triangles (SAH and the reference builder's tree):
+    16-bit references, more inner records than the LDS cache holds.  GPU == the CPU restatement bit for bit, work counters included."""
+    scene = _soup(srt, n, n).build_bvh(mode, 1984)
+    W, H, spp, depth = 56, 40, 3, 8
+    cam = srt.camera_init(W, H, 50.0, (0.5, 1.0, 16.0), (0.0, 0.0, 0.0), defocus_angle=0.6 if mode else 0.0, focus_dist=14.0)
+    out = srt.render_image(scene, cam, W, H, spp, depth, renderer=gpu, count_traversal=count_traversal)
+    plan = gpu.launch_plan()
+    assert plan["narrow_refs"] and not plan["all_cached"] and plan["n_cached"] > 0, plan
+    ref = oracle_scene_for(orc, scene, mode).render(cam, W, H, spp, depth)
+    _assert_render_matches(out, ref, "soup of %d" % n, count_traversal, n)
+    assert max(float(p.max()) for p in out["xyz"]) > 0
+
+
 @pytest.mark.parametrize("count_traversal", VARIANTS)
 @pytest.mark.parametrize("seed", range(12))
 def test_random_scenes_fuzz(srt, gpu, orc, seed, count_traversal):
