@@ -257,7 +257,7 @@ int srt_launch_plan(const srt_ctx *c, int *waves_per_cu, int *n_cached, int *all
     if (waves_per_cu) *waves_per_cu = plan.waves_per_cu;
     if (n_cached) *n_cached = plan.n_cached;
     if (all_cached) *all_cached = plan.all_cached ? 1 : 0;
-    if (narrow_refs) *narrow_refs = c->n_records <= 32767 ? 1 : 0;
+    if (narrow_refs) *narrow_refs = render_narrow_refs(c->n_records) ? 1 : 0;
     return SRT_OK;
 }
 

@@ -86,6 +86,7 @@ hipError_t launch_op_sweep(int which, const float *a, const float *b, size_t n, 
 hipError_t launch_calib(int kind, uint32_t n_blocks, uint32_t threads, uint32_t iters, float *sink, unsigned long long *cycles, const float4 *table,
                         uint32_t n_records, hipStream_t st);
 int calib_kinds();
+bool render_narrow_refs(int n_records);
 size_t render_lds_bytes(int stack_depth, int waves_per_block, int n_cached, int n_records);
 void render_launch_shape(int stack_depth, int n_records, int n_inner, int &waves_per_block, int &n_cached);
 struct LaunchPlan { int waves_per_block, blocks_per_cu, waves_per_cu, waves_per_eu, n_cached; bool all_cached; };

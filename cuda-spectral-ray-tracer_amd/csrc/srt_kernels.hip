@@ -45,7 +45,13 @@ constexpr uint32_t kBurstDropL2 = SRT_BURST_DROP_L2;
 constexpr int kInnerBurst = SRT_INNER_BURST;   // at most this many inner steps between two scheduling decisions (fully unrolled)
 constexpr uint32_t kBurstDrop = SRT_BURST_DROP;   // ... and the burst ends once fewer than 1 / kBurstDrop of its lanes are still at inner records
 static inline size_t round16(size_t v) { return (v + 15) & ~(size_t)15; }
-static inline bool narrow_refs(int n_records) { return n_records <= 32767; }   // 15 bits: a 16-bit stack slot also holds the sentinel -1
+// 16-bit child references and stack entries when the record indices fit 15 bits (a 16-bit stack slot also holds the sentinel -1).
+// SRT_WIDE_REFS=1 (test knob, read with every plan) sends small trees through the 32-bit variants as well.
+bool render_narrow_refs(int n_records) {
+    if (const char *ev = getenv("SRT_WIDE_REFS")) if (atoi(ev) != 0) return false;
+    return n_records <= 32767;
+}
+static inline bool narrow_refs(int n_records) { return render_narrow_refs(n_records); }
 static inline size_t cache_bytes(int n_cached, int n_records) { return round16((size_t)n_cached * (narrow_refs(n_records) ? 52 : 56)); }
 static inline size_t stack_slots(int stack_depth) { return (size_t)(stack_depth < 1 ? 1 : stack_depth) + kStackSentinels; }
 static inline size_t stack_bytes(int stack_depth, int n_records) { return stack_slots(stack_depth) * 64 * (narrow_refs(n_records) ? 2 : 4); }

@@ -784,6 +784,24 @@ def test_partly_cached_narrow_tree_forced_on_small_scenes(srt, gpu, orc, monkeyp
 
 
 @pytest.mark.parametrize("count_traversal", VARIANTS)
+@pytest.mark.parametrize("sid,mode,W,H,spp,depth", [SCENES[0], SCENES[2], SCENES[4], SCENES[9]])
+def test_wide_references_forced_on_small_scenes(srt, gpu, orc, monkeypatch, sid, mode, W, H, spp, depth, count_traversal):
+    """render_kernel<MODE, NARROW = false, ALL_CACHED = true>: 32-bit references with the whole inner tree in LDS.  No real tree
+    gets there (more than 32 767 records of which fewer than ~2 400 are INNER would be deeper than the LDS stack allows), but the
+    launcher instantiates it: SRT_WIDE_REFS=1 sends the small scenes through it so that every instantiated variant has run against
+    the CPU restatement."""
+    monkeypatch.setenv("SRT_WIDE_REFS", "1")
+    scene = srt.Scene.builtin(sid, 0).build_bvh(mode, 1984)
+    cam = scene.default_camera(W, H)
+    out = srt.render_image(scene, cam, W, H, spp, depth, renderer=gpu, count_traversal=count_traversal)
+    plan = gpu.launch_plan()
+    assert not plan["narrow_refs"]
+    assert plan["all_cached"] == (sid != 100)      # (scene 100's 4 802-triangle tree no longer fits LDS with 56-byte records and 4-byte stack slots)
+    ref = oracle_scene_for(orc, scene, mode).render(cam, W, H, spp, depth)
+    _assert_render_matches(out, ref, "scene %d, wide references" % sid, count_traversal, scene.n_tris)
+
+
+@pytest.mark.parametrize("count_traversal", VARIANTS)
 @pytest.mark.parametrize("n,mode", [(9000, 1), (14000, 0), (30000, 1)])
 def test_mid_size_scenes_bit_exact(srt, gpu, orc, n, mode, count_traversal):
     """The same variant reached the natural way: soups of 9 000 / 14 000 / 30 000 triangles (SAH and the reference builder's tree):
