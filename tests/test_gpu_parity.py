@@ -765,7 +765,7 @@ def _assert_render_matches(out, ref, what, count_traversal, n_tris):
 
 @pytest.mark.parametrize("count_traversal", VARIANTS)
 @pytest.mark.parametrize("cap", [0, 3])
-@pytest.mark.parametrize("sid,mode,W,H,spp,depth", [SCENES[0], SCENES[2], SCENES[3], SCENES[4], SCENES[9], SCENES[11]])
+@pytest.mark.parametrize("sid,mode,W,H,spp,depth", [SCENES[0], SCENES[2], SCENES[3], SCENES[4], SCENES[8], SCENES[9], SCENES[11]])
 def test_partly_cached_narrow_tree_forced_on_small_scenes(srt, gpu, orc, monkeypatch, sid, mode, W, H, spp, depth, cap, count_traversal):
     """render_kernel<MODE, NARROW = true, ALL_CACHED = false>: 16-bit child references, inner records beyond an LDS prefix served by
     L2 -- the variant mid-size scenes (about 5 k to 60 k triangles) launch, which neither the small test scenes (whole tree in LDS)
@@ -784,7 +784,7 @@ def test_partly_cached_narrow_tree_forced_on_small_scenes(srt, gpu, orc, monkeyp
 
 
 @pytest.mark.parametrize("count_traversal", VARIANTS)
-@pytest.mark.parametrize("sid,mode,W,H,spp,depth", [SCENES[0], SCENES[2], SCENES[4], SCENES[9]])
+@pytest.mark.parametrize("sid,mode,W,H,spp,depth", [SCENES[0], SCENES[2], SCENES[4], SCENES[8], SCENES[9]])
 def test_wide_references_forced_on_small_scenes(srt, gpu, orc, monkeypatch, sid, mode, W, H, spp, depth, count_traversal):
     """render_kernel<MODE, NARROW = false, ALL_CACHED = true>: 32-bit references with the whole inner tree in LDS.  No real tree
     gets there (more than 32 767 records of which fewer than ~2 400 are INNER would be deeper than the LDS stack allows), but the
