@@ -69,7 +69,10 @@ int main(int argc, char **argv) {
     render_manager rm(sm.getScene(), &scene_cam, &fb);
     if (pm.gpus > 1) {
         std::vector<int> devices;
-        for (int d = 0; d < pm.gpus; d++) devices.push_back(d);
+        // (test hook, as in the library: with SRT_COMM_TEST_SAME_DEVICE=1 every rank sits on device 0 -- the library honours a
+        // duplicate device only over the test transport, so a real run with this set fails loudly instead of sharing a GPU)
+        const char *same = getenv("SRT_COMM_TEST_SAME_DEVICE");
+        for (int d = 0; d < pm.gpus; d++) devices.push_back(same && same[0] == '1' ? 0 : d);
         rm.init_renderer(pm.bounce_limit, pm.n_samples, devices);
         lc.add_entry("gpus", pm.gpus);
     } else rm.init_renderer(pm.bounce_limit, pm.n_samples, pm.gpu);

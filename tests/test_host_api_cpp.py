@@ -98,6 +98,27 @@ def test_cli_driver_writes_bmp_and_log(srt, orc, tmp_path):
 
 
 @pytest.mark.gpu
+def test_cli_driver_two_and_three_ranks_mock_transport(srt, tmp_path):
+    """srt_render --gpus N: host_api.hpp's render_manager::init_renderer(bounce, spp, devices) -> srt_comm_init_all, chunks rendered
+    with srt_render_frame_multi.  On ONE GPU over the test transport (tests/cpp/mock_rccl.cpp; every rank on device 0): the BMP of a
+    2-rank and of a 3-rank run, whole-image and in 40x24 chunks, equals the single-GPU run's byte for byte."""
+    exe = os.path.join(PKG, "srt_render")
+    mock = os.path.join(ROOT, "tests", "cpp", "_build", "libmock_rccl.so")
+    if not os.path.exists(mock):
+        pytest.skip("tests/cpp/_build/libmock_rccl.so not built (__graft_entry__.build())")
+    base = ["-s", "0", "-xr", "96", "-ar", "4/3", "-ns", "12", "-bl", "8", "--save", "--no-show"]
+    def run(title, extra, env=None):
+        subprocess.check_call([exe] + base + ["-t", title] + extra, cwd=str(tmp_path), timeout=180, env=env)
+        return (tmp_path / "renders" / (title + ".bmp")).read_bytes()
+    env = dict(os.environ, SRT_RCCL_LIB=mock, SRT_COMM_TEST_SAME_DEVICE="1")
+    for chunks in ([], ["-xc", "40", "-yc", "24"]):
+        one = run("one" + str(len(chunks)), chunks)
+        assert one[:2] == b"BM" and len(one) == 54 + 96 * 72 * 3 and any(one[54:])
+        for n in (2, 3):
+            assert run("ranks%d_%d" % (n, len(chunks)), chunks + ["--gpus", str(n)], env) == one, (n, chunks)
+
+
+@pytest.mark.gpu
 def test_cli_driver_reports_failure(srt, tmp_path):
     """A render that cannot run (device index that does not exist; more GPUs than the box has) must not exit 0 with a black
     image: the reference dies in checkCudaErrors -> exit(99) (utils/cuda_utility.cu:8-18), this driver returns non-zero."""
