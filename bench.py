@@ -578,7 +578,7 @@ def lane_ops_entry(scene_id):
     return None, None
 
 
-def kernel_tie(renderer, entry, lib_path):
+def kernel_tie(renderer, entry, lib_path, tree=None):
     """which kernel variant the uploaded scene launches, the hash of its machine code in the LOADED library (tools/kernel_id.py: the
     kernel's bytes in the gfx950 code object; for PMC entries that predate it, the hash of the build's ISA listing), and how an
     imported PMC entry relates to it"""
@@ -602,18 +602,20 @@ def kernel_tie(renderer, entry, lib_path):
             tie = "UNVERIFIED (%s)" % note
         elif theirs is None:
             tie = "UNVERIFIED (the imported PMC pass predates the hash tie)"
+        elif theirs == mine and tree is not None and entry.get("tree_sha256") not in (None, tree):
+            tie = "STALE (PMC pass was taken on this kernel binary but on another tree of the scene: %s, this run traverses %s)" % (entry["tree_sha256"][:16], tree[:16])
         elif theirs == mine:
-            tie = "current (PMC pass taken on this kernel binary: %s sha256 %s)" % (what, mine[:16])
+            tie = "current (PMC pass taken on this kernel binary: %s sha256 %s%s)" % (what, mine[:16], ", and on this tree: sha256 %s" % tree[:16] if tree is not None and entry.get("tree_sha256") == tree else "")
         else:
             tie = "STALE (PMC pass was taken on kernel %s, this library is %s: %s)" % (theirs[:16], mine[:16], what)
     return plan, variant, hashes, tie
 
 
-def small_roofline(renderer, scene_id, rays_per_launch, kms, lib_path):
+def small_roofline(renderer, scene_id, rays_per_launch, kms, lib_path, tree=None):
     """frac_arch of a secondary workload: imported lane-ops per ray of ITS kernel variant / scene (hash-tied) x live rays / live kernel time"""
     entry, entry_file = lane_ops_entry(scene_id)
-    plan, variant, hashes, tie = kernel_tie(renderer, entry, lib_path)
-    out = {"kernel": variant, "kernel_code_sha256": hashes["code_sha256"], "kernel_isa_sha256": hashes["isa_listing_sha256"], "frac_arch": None, "achieved_source": None}
+    plan, variant, hashes, tie = kernel_tie(renderer, entry, lib_path, tree)
+    out = {"kernel": variant, "tree_sha256": tree, "kernel_code_sha256": hashes["code_sha256"], "kernel_isa_sha256": hashes["isa_listing_sha256"], "frac_arch": None, "achieved_source": None}
     if entry is not None:
         ach = rays_per_launch * entry["lane_ops_per_ray"] / (kms * 1e-3) / 1e9
         out.update(achieved=ach, unit="G lane-op/s", frac_arch=ach / ARCH_PEAK_GLANEOPS, lanes_per_valu_instruction=entry.get("lanes_per_valu_instruction"),
@@ -624,12 +626,45 @@ def small_roofline(renderer, scene_id, rays_per_launch, kms, lib_path):
     return out
 
 
+PROFILE_ORDER = True      # --no-profile-order clears it
+
+
+def tree_sha256(scene):
+    """identity of the tree a scene is traversed with (topology, child order, boxes): an imported per-ray counter figure belongs to
+    the kernel AND the tree it was taken on"""
+    import hashlib
+    import numpy as np
+    h = hashlib.sha256()
+    for a in scene.bvh():
+        h.update(np.ascontiguousarray(a).tobytes())
+    return h.hexdigest()
+
+
+def build_scene(srt, job, scene_id, bvh, W, H, depth):
+    """The scene as every frame traverses it, built outside any timed region (the reference builds its tree in create_bvh_kernel before
+    the render, scene/scene.cu:9-20).  For this build's own SAH trees, when the launch is throughput-bound (at least 6 pixels per
+    persistent lane of a rank's launch): topology optimisation + child order from a probe frame (srt.tune_tree_for_throughput).
+    Launches with fewer pixels per lane are bound by their longest pixel chain, which a tree with less TOTAL work does not shorten
+    (measured slower), and keep the builder's tree.  Deterministic: every rank arrives at the same tree."""
+    scene = srt.Scene.builtin(scene_id, 0).build_bvh(bvh, 1984)
+    if bvh != 1:
+        return scene, "the reference builder's tree"
+    r = job.local[0]
+    r.upload_scene(scene)
+    ppl = srt.pixels_per_lane(r, W, H, job.world)
+    if not PROFILE_ORDER:
+        return scene, "SAH builder's tree, nearer child to the camera first (--no-profile-order)"
+    if ppl < 6.0:
+        return scene, "SAH builder's tree, nearer child to the camera first (%.1f pixels per lane: chain-bound launch, no throughput tuning)" % ppl
+    return scene, "SAH builder's tree tuned for throughput (%.1f pixels per lane): %s" % (ppl, srt.tune_tree_for_throughput(r, scene, W, H, depth))
+
+
 def secondary_workload(srt, job, scene_id, bvh, W, H, spp, depth, with_roofline=True):
     """one frame of another BASELINE configuration on the same ranks, outside the headline's timed region"""
     t_build = time.time()
     ok, err = 1.0, None
     try:
-        scene = srt.Scene.builtin(scene_id, 0).build_bvh(bvh, 1984)
+        scene, order_note = build_scene(srt, job, scene_id, bvh, W, H, depth)
         cam = scene.default_camera(W, H)
         job.upload(scene, cam)
     except Exception as e:      # noqa: BLE001
@@ -643,7 +678,7 @@ def secondary_workload(srt, job, scene_id, bvh, W, H, spp, depth, with_roofline=
     rec = None
     if job.rank == 0:
         rec = {"workload": "%s (%d tris, %d BVH nodes), %dx%d, %d spp, depth %d" % (SCENE_NAMES.get(scene_id, "scene %d" % scene_id), scene.n_tris, scene.n_nodes, W, H, spp, depth),
-               "scene_id": scene_id, "bvh": "SAH" if bvh == 1 else "reference builder",
+               "scene_id": scene_id, "bvh": "SAH" if bvh == 1 else "reference builder", "child_order": order_note,
                "value": tf["total_rays"] / tf["elapsed"] / 1e6, "unit": "Mray/s", "frames": 1, "ms": tf["elapsed"] * 1e3, "kernel_ms": tf["kms"],
                "rays": tf["total_rays"], "V": tc["V"], "T": tc["T"], "rays_per_path": tc["rays_per_path"],
                "nan_direction_rays_pct": 100.0 * tc["nan_share"], "algorithmic_bytes_per_ray": tc["b_ray"],
@@ -652,7 +687,7 @@ def secondary_workload(srt, job, scene_id, bvh, W, H, spp, depth, with_roofline=
             rec["per_rank_kernel_ms"] = [round(x[0], 3) for x in tf["rows"]]
             rec["per_rank_rays"] = [int(x[1]) for x in tf["rows"]]
         if with_roofline and job.world == 1:
-            rec["roofline"] = small_roofline(job.root, scene_id, tf["rays_rank0"], tf["kms"], srt.binding.LIB_PATH)
+            rec["roofline"] = small_roofline(job.root, scene_id, tf["rays_rank0"], tf["kms"], srt.binding.LIB_PATH, tree_sha256(scene))
             rec["frac_arch"] = rec["roofline"]["frac_arch"]
             rec["achieved_source"] = rec["roofline"]["achieved_source"]
     return rec
@@ -671,6 +706,7 @@ def main():
     ap.add_argument("--bvh", type=int, default=1)              # SRT_BVH_SAH for the synthetic scenes
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-calibration", action="store_true", help="skip the issue-rate microkernel and the copy-rate measurement (profiling passes)")
+    ap.add_argument("--no-profile-order", action="store_true", help="keep the SAH builder's child order (nearer child to the camera first) instead of the profiled one")
     ap.add_argument("--no-other-configs", action="store_true", help="skip cfg 2 / cfg 4 / cfg 5's scene at 512 spp (N = 1 block `other_configs`)")
     ap.add_argument("--cfg5-spp", type=int, default=4096, help="samples of the cfg 5 sub-record (BASELINE: 4096); 0 = skip it")
     ap.add_argument("--cfg5-size", default="3840x2160", help="image size of the cfg 5 sub-record (BASELINE: 3840x2160)")
@@ -678,6 +714,8 @@ def main():
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="rehearsal of the process-per-GPU control flow on ONE GPU: every rank uses cuda:0, torch.distributed runs on gloo and the gather goes through host memory (never used for reported numbers)")
     args = ap.parse_args()
+    global PROFILE_ORDER
+    PROFILE_ORDER = not args.no_profile_order
 
     import torch
 
@@ -725,8 +763,9 @@ def main():
         job = OneGpu(srt, torch, torch.cuda.current_device())
 
     # ---- inputs, resident in HBM before the timed region ------------------------------------------------
-    scene = srt.Scene.builtin(args.scene, 0).build_bvh(args.bvh, 1984)
     W, H = args.width, args.height
+    scene, order_note = build_scene(srt, job, args.scene, args.bvh, W, H, args.depth)
+    scene_tree = tree_sha256(scene)
     cam = scene.default_camera(W, H)
     job.upload(scene, cam)
 
@@ -760,11 +799,12 @@ def main():
         b_ray = tc["b_ray"]
         # ---- roofline of the dominant kernel (render_kernel) on this rank -------------------------------------------
         entry, entry_file = lane_ops_entry(args.scene)
-        plan, variant, hashes, tie = kernel_tie(job.root, entry, srt.binding.LIB_PATH)
+        plan, variant, hashes, tie = kernel_tie(job.root, entry, srt.binding.LIB_PATH, scene_tree)
         roof = {"bound": "valu-issue", "achieved": None, "peak": None, "unit": "G lane-op/s", "frac": None, "frac_arch": None, "traffic": None,
                 "peak_arch": ARCH_PEAK_GLANEOPS,
                 "peak_arch_source": "256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz (MI355X_MICROARCH.md: a wave64 VALU instruction issues over 2 cycles; 157.3 TFLOP/s fp32 FMA / 2)"}
         roof["kernel_code_sha256"], roof["kernel_isa_sha256"] = hashes["code_sha256"], hashes["isa_listing_sha256"]
+        roof["tree_sha256"] = scene_tree
         roof["kernel"] = variant + ", %d waves per CU, %d of the inner records in LDS" % (plan["waves_per_cu"], plan["n_cached"])
         roof["library"] = os.path.relpath(srt.binding.LIB_PATH, ROOT)
         if entry is not None:
@@ -805,7 +845,7 @@ def main():
             "config": {"workload": "%s (%d tris, %d BVH nodes), %dx%d, %d spp, depth %d" %
                                    (SCENE_NAMES.get(args.scene, "scene %d" % args.scene), scene.n_tris, scene.n_nodes, W, H, args.spp, args.depth),
                        "scene_id": args.scene,
-                       "bvh": BVH_NAMES.get(args.bvh, str(args.bvh)),
+                       "bvh": BVH_NAMES.get(args.bvh, str(args.bvh)), "child_order": order_note, "tree_sha256": scene_tree,
                        "nan_direction_rays": "%.2f %% of the counted rays have a NaN direction (Sellmeier quirk Q1) and are answered 'miss' without walking the tree" % (100.0 * tc["nan_share"]),
                        "tiles": "8x8 px per wave, rank = tile % n_gpus", "gather": job.gather_via, "launch_mode": job.launch_mode},
             "mpath_per_s": (W * H * args.spp * steps) / elapsed / 1e6,

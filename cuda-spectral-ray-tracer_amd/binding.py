@@ -78,6 +78,7 @@ PROTOTYPES = {
     "srt_rotation_matrix": (_i, [_f, _i, _fp]),
     "srt_scene_build_bvh": (_i, [_vp, _i, _u64]),
     "srt_scene_order_children": (_i, [_vp, _fp]),
+    "srt_scene_optimise_bvh": (_i, [_vp, C.c_int]),
     "srt_scene_node_count": (_sz, [_vp]),
     "srt_scene_bvh_depth": (_i, [_vp]),
     "srt_scene_get_bvh": (_i, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), _fp]),
@@ -101,6 +102,7 @@ PROTOTYPES = {
     "srt_read_fb_rowmajor": (_i, [_vp, _fp, _fp, _fp, _u32, _u32]),
     "srt_read_fb_aux": (_i, [_vp, _i, _fp, _fp, _fp]),
     "srt_get_tile_costs": (_i, [_vp, C.POINTER(C.c_uint32), _sz]),
+    "srt_order_children_by_profile": (_i, [_vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]),
     "srt_get_stats": (_i, [_vp, C.POINTER(Stats)]),
     "srt_set_count_traversal": (_i, [_vp, _i]),
     "srt_get_wave_debug": (_i, [_vp, C.POINTER(C.c_uint32), _sz]),
@@ -109,6 +111,7 @@ PROTOTYPES = {
     "srt_device_op_sweep": (_i, [_vp, _i, _fp, _fp, _sz, _fp]),
     "srt_calibrate": (_i, [_vp, _i, _u32, _u32, C.POINTER(Calibration)]),
     "srt_ctx_device": (_i, [_vp]),
+    "srt_ctx_cu_count": (_i, [_vp]),
     "srt_comm_init_all": (_i, [C.POINTER(_i), _i, C.POINTER(_vp)]),
     "srt_comm_unique_id": (_i, [C.POINTER(C.c_ubyte)]),
     "srt_comm_init_rank": (_i, [_vp, C.POINTER(C.c_ubyte), _u32, _u32, C.POINTER(_vp)]),

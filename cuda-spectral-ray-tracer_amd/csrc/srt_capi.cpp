@@ -75,6 +75,7 @@ struct srt_ctx {
     bool timed = false;
     uint64_t last_paths = 0;
     float *d_rowmajor = nullptr;                        // row-major staging image of srt_read_fb_rowmajor (3 planes)
+    OrderProfile order_profile = {};                    // non-zero magic: the next instrumented launch collects the child-order profile
     uint32_t *d_wave_debug = nullptr;                   // instrumented launches: 4 words per wave
     uint32_t wave_debug_waves = 0;
     uint32_t rowmajor_w = 0, rowmajor_h = 0;
@@ -203,6 +204,7 @@ void srt_destroy(srt_ctx *c) {
 }
 
 int srt_ctx_device(const srt_ctx *ctx) { return ctx ? ctx->device : -1; }
+int srt_ctx_cu_count(const srt_ctx *ctx) { return ctx ? ctx->n_cu : -1; }
 
 const char *srt_last_error(const srt_ctx *ctx) { return ctx ? ctx->err.c_str() : global_error(); }
 
@@ -394,11 +396,20 @@ int srt_render_chunk(srt_ctx *c, uint32_t width, uint32_t height, uint32_t offx,
         const uint32_t n_waves = (uint32_t)c->n_cu * (uint32_t)plan.waves_per_cu;
         if (n_waves > c->wave_debug_waves) {
             if (c->d_wave_debug) { (void)hipFree(c->d_wave_debug); c->d_wave_debug = nullptr; c->wave_debug_waves = 0; }
-            HIP_TRY(c, hipMalloc((void **)&c->d_wave_debug, (size_t)n_waves * 4 * sizeof(uint32_t)));
+            HIP_TRY(c, hipMalloc((void **)&c->d_wave_debug, (size_t)n_waves * 4 * sizeof(uint32_t) + sizeof(OrderProfile)));      // (+ the profile header, srt_internal.h)
             c->wave_debug_waves = n_waves;
         }
-        HIP_TRY(c, hipMemsetAsync(c->d_wave_debug, 0, (size_t)c->wave_debug_waves * 4 * sizeof(uint32_t), st));
+        HIP_TRY(c, hipMemsetAsync(c->d_wave_debug, 0, (size_t)c->wave_debug_waves * 4 * sizeof(uint32_t) + sizeof(OrderProfile), st));
         p.wave_debug = c->d_wave_debug;
+        {
+            // the kernel looks for the header behind the words of the waves it was LAUNCHED with
+            uint32_t launched = std::min<uint32_t>(n_waves, p.queue_rows_bound);
+            const uint32_t wpb = (c->waves_per_cu > 0 && c->waves_per_cu < 16 && plan.waves_per_block == 16) ? c->waves_per_cu : (uint32_t)plan.waves_per_block;      // (as launch_render_cached)
+            if (wpb != (uint32_t)plan.waves_per_block) launched = std::min<uint32_t>((uint32_t)c->n_cu * wpb, p.queue_rows_bound);
+            launched = (launched + wpb - 1) / wpb * wpb;
+            if (c->order_profile.magic == kOrderProfileMagic && launched <= c->wave_debug_waves)
+                HIP_TRY(c, hipMemcpyAsync(c->d_wave_debug + 4 * (size_t)launched, &c->order_profile, sizeof(OrderProfile), hipMemcpyHostToDevice, st));
+        }
     }
     RoctxRange range_render("srt render_kernel");
     HIP_TRY(c, hipEventRecord(c->ev0, st));     // ev0..ev1 bracket the render kernel alone (roofline.achieved)
@@ -548,6 +559,98 @@ int srt_get_wave_debug(srt_ctx *c, uint32_t *out, size_t n_waves) {
     HIP_TRY(c, hipDeviceSynchronize());
     HIP_TRY(c, hipMemcpy(out, c->d_wave_debug, n_waves * 4 * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return SRT_OK;
+}
+
+// Child order from a profile of the real rays.  The traversal is the reference's fixed left-first walk (bvh.cu:154-160), so which
+// child of a node is visited first is a property of the TREE -- and for every ray whose closest hit lies under one child while the
+// other child's box lies on its path beyond that hit, visiting the hit's side first lets closest_so_far prune the other subtree.
+// The builder's rule (nearer child to the camera first) is right for camera rays; this call measures instead: one instrumented
+// probe frame of the context's camera (width x height, spp, bounce_limit) in which every finished closest-hit query walks from
+// its triangle's leaf to the root and notes, at every ancestor whose OTHER child's box the ray meets only beyond the hit, under
+// which child the hit lay.  Children are swapped wherever the right one won more often (at least `min_samples` such rays at the
+// node; elsewhere the existing order stays).  A second probe frame then checks the work counters (node records + 2 x triangle
+// tests of the same frame, deterministic): if the new order is not cheaper the swaps are undone (cfg 5's mesh: no gain -> kept as
+// built).  The scene is left (re-)ordered and uploaded; topology, boxes and depth do not change, and like any change of the tree
+// it can only alter a result where two triangles tie exactly in t (Q11).  n_swapped (optional) = nodes changed (0 after an undo).
+int srt_order_children_by_profile(srt_ctx *c, srt_scene *s, uint32_t width, uint32_t height, uint32_t spp, uint32_t bounce_limit,
+                                  uint32_t min_samples, uint32_t *n_swapped) {
+    if (n_swapped) *n_swapped = 0;
+    if (!c || !s || !s->bvh_valid) return fail(c, SRT_ERR_INVALID, "srt_order_children_by_profile: null argument / BVH not built");
+    if (!c->camera_ready) return fail(c, SRT_ERR_INVALID, "srt_order_children_by_profile: set the camera first (srt_set_camera)");
+    if (width == 0 || height == 0 || spp == 0) return fail(c, SRT_ERR_INVALID, "srt_order_children_by_profile: empty probe frame");
+    const size_t n_nodes = s->nodes.size(), n_tris = s->raw.size();
+    int rc = srt_upload_scene(c, s);
+    if (rc != SRT_OK || n_nodes < 3) return rc;
+    std::vector<int32_t> leaf(n_tris, 0), up(n_nodes, -1);
+    std::vector<float> sibbox(6 * n_nodes, 0.f);
+    for (size_t k = 0; k < n_nodes; k++) {
+        const BvhNode &nd = s->nodes[k];
+        if (nd.prim >= 0) { leaf[(size_t)nd.prim] = (int32_t)k; continue; }
+        up[(size_t)nd.left] = (int32_t)(2 * k); up[(size_t)nd.right] = (int32_t)(2 * k + 1);
+        memcpy(&sibbox[6 * (size_t)nd.left], s->nodes[(size_t)nd.right].box, 6 * sizeof(float));
+        memcpy(&sibbox[6 * (size_t)nd.right], s->nodes[(size_t)nd.left].box, 6 * sizeof(float));
+    }
+    int32_t *d_leaf = nullptr, *d_up = nullptr; float *d_sib = nullptr; uint32_t *d_cnt = nullptr;
+    auto release = [&]() { (void)hipFree(d_leaf); (void)hipFree(d_up); (void)hipFree(d_sib); (void)hipFree(d_cnt); c->order_profile = OrderProfile{}; };
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipError_t e = hipMalloc((void **)&d_leaf, std::max<size_t>(n_tris, 1) * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&d_up, n_nodes * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&d_sib, 6 * n_nodes * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void **)&d_cnt, 2 * n_nodes * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemcpy(d_leaf, leaf.data(), n_tris * sizeof(int32_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_up, up.data(), n_nodes * sizeof(int32_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_sib, sibbox.data(), 6 * n_nodes * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(d_cnt, 0, 2 * n_nodes * sizeof(uint32_t));
+    if (e != hipSuccess) { release(); return hip_fail(c, e, "srt_order_children_by_profile: device buffers"); }
+    // instrumented probe frames on this context alone (its partition and counter setting are restored afterwards)
+    const bool counting = c->count_traversal;
+    const uint32_t rank = c->rank, world = c->world;
+    const uint32_t tx = 28, ty = 16, bx = width / tx + 1, by = height / ty + 1;      // the reference's grid (render_manager.cu:84-94)
+    auto probe_frame = [&](bool collect, unsigned long long &work) -> int {
+        c->order_profile = OrderProfile{};
+        if (collect) {
+            c->order_profile.magic = kOrderProfileMagic; c->order_profile.leaf = d_leaf; c->order_profile.up = d_up;
+            c->order_profile.sibbox = d_sib; c->order_profile.cnt = d_cnt; c->order_profile.n_nodes = n_nodes;
+        }
+        c->count_traversal = true; c->rank = 0; c->world = 1;
+        int r = srt_init_device_params(c, tx, ty, bx, by, width, height, spp, bounce_limit, 1984);
+        if (r == SRT_OK) r = srt_render_chunk(c, width, height, 0, 0, nullptr);
+        if (r == SRT_OK) r = srt_synchronize(c);
+        c->count_traversal = counting; c->rank = rank; c->world = world;
+        c->order_profile = OrderProfile{};
+        c->params_ready = false;      // (the probe's RNG state and grid are not the caller's: srt_init_device_params comes next)
+        if (r != SRT_OK) return r;
+        unsigned long long h[kCounters];
+        const hipError_t he = hipMemcpy(h, c->d_counters, sizeof(h), hipMemcpyDeviceToHost);
+        if (he != hipSuccess) return hip_fail(c, he, "srt_order_children_by_profile: counters");
+        work = h[1] + 2ull * h[2];      // node records visited + 2 x triangle tests
+        return SRT_OK;
+    };
+    unsigned long long work_before = 0, work_after = 0;
+    rc = probe_frame(true, work_before);
+    std::vector<uint32_t> cnt(2 * n_nodes, 0u);
+    if (rc == SRT_OK) { e = hipMemcpy(cnt.data(), d_cnt, cnt.size() * sizeof(uint32_t), hipMemcpyDeviceToHost); if (e != hipSuccess) rc = hip_fail(c, e, "srt_order_children_by_profile: read back"); }
+    if (rc != SRT_OK) { release(); return rc; }
+    const uint32_t *won = cnt.data();      // [node * 2 + side]: hits under that child with the sibling's box beyond the hit
+    std::vector<uint32_t> swapped_nodes;
+    for (size_t k = 0; k < n_nodes; k++) {
+        BvhNode &nd = s->nodes[k];
+        if (nd.prim >= 0) continue;
+        const uint32_t l = won[2 * k], r = won[2 * k + 1];
+        if (l + r >= std::max<uint32_t>(min_samples, 1u) && r > l) { std::swap(nd.left, nd.right); swapped_nodes.push_back((uint32_t)k); }
+    }
+    if (!swapped_nodes.empty()) {
+        rc = srt_upload_scene(c, s);
+        if (rc == SRT_OK) rc = probe_frame(false, work_after);
+        if (rc == SRT_OK && work_after >= work_before) {      // not cheaper on the very frame it was derived from: undo
+            for (uint32_t k : swapped_nodes) std::swap(s->nodes[k].left, s->nodes[k].right);
+            swapped_nodes.clear();
+            rc = srt_upload_scene(c, s);
+        }
+    }
+    release();
+    if (rc == SRT_OK && n_swapped) *n_swapped = (uint32_t)swapped_nodes.size();
+    return rc;
 }
 
 int srt_set_count_traversal(srt_ctx *c, int on) {

@@ -64,6 +64,19 @@ struct RenderParams {
     uint32_t *wave_debug;                 // instrumented build, optional: 4 words per wave (see srt_get_wave_debug)
 };
 
+// Child-order profile of an instrumented launch (srt_order_children_by_profile): the pointers travel in a header behind the per-wave
+// words of RenderParams::wave_debug (4 words per launched wave, then this struct) so that RenderParams -- the kernel argument of every
+// variant -- stays as it is.  magic == kOrderProfileMagic marks a launch that collects the profile.
+struct OrderProfile {
+    unsigned long long magic;
+    const int32_t *leaf;       // per triangle: node index of its leaf
+    const int32_t *up;         // per node: parent node * 2 + (1 if the node is the right child), -1 for the root
+    const float *sibbox;       // per node: the box of its sibling (xmin xmax ymin ymax zmin zmax)
+    uint32_t *cnt;             // [parent * 2 + side]: closest hits found under that child while the sibling's box lay on the ray beyond the hit
+    unsigned long long n_nodes;
+};
+constexpr unsigned long long kOrderProfileMagic = 0x5352544f52444552ull;
+
 struct ScatterParams {
     const float *gathered;     // [rank][group (groups of them)][tiles_padded][plane of the group][lane]
     uint32_t groups;           // 1: only the quantised framebuffer was gathered (12 B / pixel); 3: the parity planes too

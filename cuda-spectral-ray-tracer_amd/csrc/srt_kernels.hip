@@ -216,6 +216,9 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
     // slot is not part of the row's share, and the lanes that finish early, stay PARKED until every pixel of the wave is
     // done -- a wave that refilled itself with other pixels would slow the expensive chains down again.
     bool parked = false, exclusive = false;
+    OrderProfile prof;      // instrumented build only: see srt_internal.h
+    prof.magic = 0;
+    if (COUNT && P.wave_debug) prof = *reinterpret_cast<const OrderProfile *>(P.wave_debug + 4u * (size_t)gridDim.x * (blockDim.x >> 6));
     unsigned long long t_shade = 0, t_inner = 0, t_fringe = 0, t_mark = 0;   // instrumented build: wave cycles per phase
     if (COUNT) t_mark = __builtin_amdgcn_s_memtime();
     const unsigned long long t_born = t_mark;
@@ -249,6 +252,23 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
                 if (tv.hit < 0) {
                     end_path = true;        // miss: r.mul_spectrum(background) and stop
                 } else {
+                    if (COUNT && P.wave_debug && prof.magic == kOrderProfileMagic) {
+                        // child-order profile: walk from the hit triangle's leaf to the root; at every ancestor whose OTHER child's box
+                        // lies on the ray beyond the hit, note under which child the hit lay (visited first, that side prunes the other)
+                        int k = prof.leaf[tv.hit];
+                        for (int guard = 0; guard < 96; guard++) {
+                            const int up = prof.up[k];
+                            if (up < 0) break;
+                            const float *b = prof.sibbox + 6 * (size_t)k;
+                            const float x0 = (b[0] - ro.x) * inv.x, x1 = (b[1] - ro.x) * inv.x;
+                            const float y0 = (b[2] - ro.y) * inv.y, y1 = (b[3] - ro.y) * inv.y;
+                            const float z0 = (b[4] - ro.z) * inv.z, z1 = (b[5] - ro.z) * inv.z;
+                            const float e = fmaxf(fmaxf(fmaxf(0.0f, fminf(x0, x1)), fminf(y0, y1)), fminf(z0, z1));
+                            const float m = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+                            if (e <= m && e > tv.c) atomicAdd(&prof.cnt[up], 1u);
+                            k = up >> 1;
+                        }
+                    }
                     // rebuild the hit record from (t, triangle): tri::hit tail (tri.cu:36-39) + set_face_normal.  ONE round of
                     // loads: the triangle's shading record carries the normal, the material index and the material scalars.
                     const uint32_t srec = __umul24((uint32_t)tv.hit, 48u);      // (full-rate 24-bit multiply; < 2^24 triangles)

@@ -83,6 +83,11 @@ class Scene:
         B.check(B.lib().srt_scene_build_bvh(self._h, int(mode), int(seed)))
         return self
 
+    def optimise_bvh(self, passes=3):
+        """insertion-based topology optimisation of the built tree (srt_scene_optimise_bvh): for throughput-bound launches"""
+        B.check(B.lib().srt_scene_optimise_bvh(self._h, passes))
+        return self
+
     def order_children(self, eye):
         """Re-order every node's children for a viewpoint (nearer child first); upload the scene again afterwards."""
         e = (C.c_float * 3)(*[float(x) for x in eye])

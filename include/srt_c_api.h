@@ -167,6 +167,12 @@ SRT_API int srt_scene_build_bvh(srt_scene *s, int mode, uint64_t seed);
  * children by distance to the scene's default camera.  For another viewpoint: re-order the built tree for `eye` (the nearer
  * child becomes the left one; topology, boxes and depth unchanged), then srt_upload_scene again. */
 SRT_API int srt_scene_order_children(srt_scene *s, const float eye[3]);
+/* Topology optimisation of a built tree for throughput-bound launches (host only; no reference counterpart -- the tree is an input
+ * of bvh::hit, bvh/bvh.cu:98-166): `passes` rounds of insertion-based optimisation (every subtree is taken out and put back where
+ * it adds the least surface area; 3 rounds converge), then boxes, depth and the builder's child order again.  Fewer node records per
+ * ray on average; NOT a cheaper worst pixel -- measured slower on launches bound by their longest pixel (few pixels per lane), so it
+ * is a call of its own and not part of srt_scene_build_bvh.  Upload the scene afterwards. */
+SRT_API int srt_scene_optimise_bvh(srt_scene *s, int passes);
 SRT_API size_t srt_scene_node_count(const srt_scene *s);
 SRT_API int srt_scene_bvh_depth(const srt_scene *s);
 /* Pre-order dump (same convention as the oracle): left/right = pre-order ranks or -1, prim = original
@@ -241,6 +247,16 @@ SRT_API int srt_read_fb_aux(srt_ctx *ctx, int which, float *p0, float *p1, float
 /* Scheduling introspection: per-local-tile traversal cost measured by the probe of the last ordered launch (n = tiles_local; n = 2 *
  * tiles_local: followed by the cost of every tile's most expensive pixel -- one pixel is one sequential chain). */
 SRT_API int srt_get_tile_costs(srt_ctx *ctx, uint32_t *out, size_t n);
+/* Child order of a built tree from a profile of the real rays (no reference counterpart: the reference's bvh::hit, bvh/bvh.cu:98-166,
+ * always descends left first, so the order is a property of the tree it is given).  Renders ONE instrumented probe frame of the
+ * context's camera (width x height, spp, bounce_limit; srt_set_camera first) in which every closest-hit query notes, at each
+ * ancestor of the triangle it found, whether the other child's box lay on the ray beyond the hit -- the rays for which the visiting
+ * order decides whether that subtree is pruned -- and swaps the children of every node where the right child won more often (at
+ * least min_samples such rays; other nodes keep their order).  The scene is left re-ordered AND uploaded to ctx; topology, boxes,
+ * depth unchanged; results can only differ where two triangles tie exactly in t.  Call srt_init_device_params afterwards (the
+ * probe used the context's RNG state).  n_swapped may be NULL. */
+SRT_API int srt_order_children_by_profile(srt_ctx *ctx, srt_scene *scene, uint32_t width, uint32_t height, uint32_t spp,
+                                          uint32_t bounce_limit, uint32_t min_samples, uint32_t *n_swapped);
 SRT_API int srt_get_stats(srt_ctx *ctx, srt_stats *out);       /* counters of the last srt_render_chunk */
 SRT_API int srt_set_count_traversal(srt_ctx *ctx, int on);     /* 1: instrumented kernel also counts V / T */
 /* Instrumented launches only (diagnostics of the tail of a launch): 4 words per persistent wave -- [0] its life time and [1] the
@@ -256,7 +272,9 @@ SRT_API int srt_trace_rays(srt_ctx *ctx, const float *rays, size_t n, float *out
  * sweep"); used to prove the device's + - * / sqrt fmin cast and srt_powf bits equal the host's. */
 SRT_API int srt_device_op_sweep(srt_ctx *ctx, int which, const float *a, const float *b, size_t n, float *out);
 
-SRT_API int srt_ctx_device(const srt_ctx *ctx);               /* HIP device index of the context */
+SRT_API int srt_ctx_device(const srt_ctx *ctx);
+/* compute units of the context's GPU (a render launch keeps srt_launch_plan's waves_per_cu x 64 pixels in flight on each) */
+SRT_API int srt_ctx_cu_count(const srt_ctx *ctx);               /* HIP device index of the context */
 
 /* ---------------------------------------------------------------------------------------------------
  * Multi-GPU.  The reference's caller renders chunk after chunk on ONE GPU

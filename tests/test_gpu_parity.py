@@ -739,6 +739,59 @@ def test_custom_scenes_edge_cases(srt, gpu, orc, case, count_traversal):
         assert max(float(p.max()) for p in out["xyz"]) > 0       # the camera sees something
 
 
+@pytest.mark.parametrize("optimised", [False, True], ids=["top-down tree", "after srt_scene_optimise_bvh"])
+@pytest.mark.parametrize("count_traversal", VARIANTS)
+def test_profiled_child_order_bit_exact(srt, gpu, orc, count_traversal, optimised):
+    """srt_order_children_by_profile: the children of the SAH tree re-ordered from one instrumented probe frame (which child held the
+    closest hit while the other child's box lay beyond it).  Same nodes, same boxes, same depth, fewer node records + triangle tests
+    on the probe frame -- and, the tree being an input of the traversal, GPU == CPU restatement on the re-ordered tree bit for bit
+    (the restatement walks the tree it is given), both kernel builds."""
+    scene = srt.Scene.builtin(srt.SCENE_RANDOM_SPHERES, 0).build_bvh(srt.BVH_SAH, 1984)
+    if optimised:
+        scene.optimise_bvh(3)      # (the two steps of srt.tune_tree_for_throughput, one after the other)
+    l0, r0, p0, b0 = [np.array(a) for a in scene.bvh()]
+    depth0 = scene.bvh_depth
+    W, H, spp, depth = 120, 68, 6, 16
+    cam = scene.default_camera(W, H)
+    gpu.set_camera(cam)
+    before = srt.render_image(scene, cam, W, H, spp, depth, renderer=gpu, count_traversal=True)["stats"]
+    n = gpu.order_children_by_profile(scene, W, H, spp, depth, min_samples=4)
+    assert n > 0
+    l1, r1, p1, b1 = [np.array(a) for a in scene.bvh()]
+    assert scene.bvh_depth == depth0 and len(p1) == len(p0) and sorted(p1[p1 >= 0].tolist()) == sorted(p0[p0 >= 0].tolist())
+    assert np.array_equal(np.sort(b0.reshape(-1, 6), axis=0), np.sort(b1.reshape(-1, 6), axis=0)) and not np.array_equal(b0, b1)
+    out = srt.render_image(scene, cam, W, H, spp, depth, renderer=gpu, count_traversal=count_traversal)
+    ref = oracle_scene_for(orc, scene, 1).render(cam, W, H, spp, depth)
+    _assert_render_matches(out, ref, "profiled child order", count_traversal, scene.n_tris)
+    if count_traversal:
+        st = out["stats"]
+        assert st["node_visits"] + 2 * st["tri_tests"] < before["node_visits"] + 2 * before["tri_tests"]
+    # a second call on the same frame finds nothing left to swap (the statistic does not depend on the order)
+    assert gpu.order_children_by_profile(scene, W, H, spp, depth, min_samples=4) == 0
+
+
+def test_profiled_child_order_never_makes_the_probe_frame_worse(srt, gpu, orc):
+    """The call checks its own result on the probe frame and undoes the swaps when the work counters did not fall: whatever it
+    returns, the frame's node records + 2 x triangle tests are not above the builder's order's; 0 swaps = the tree is untouched."""
+    for sid, mode in ((srt.SCENE_PRISM, srt.BVH_REFERENCE), (srt.SCENE_CORNELL, srt.BVH_REFERENCE), (srt.SCENE_TRIS, srt.BVH_SAH)):
+        scene = srt.Scene.builtin(sid, 0).build_bvh(mode, 1984)
+        tree0 = [np.array(a).copy() for a in scene.bvh()]
+        W, H, spp, depth = 64, 48, 4, 8
+        cam = scene.default_camera(W, H)
+        before = srt.render_image(scene, cam, W, H, spp, depth, renderer=gpu, count_traversal=True)["stats"]
+        gpu.set_camera(cam)
+        n = gpu.order_children_by_profile(scene, W, H, spp, depth, min_samples=2)
+        after = srt.render_image(scene, cam, W, H, spp, depth, renderer=gpu, count_traversal=True)
+        cost = lambda st: st["node_visits"] + 2 * st["tri_tests"]
+        assert cost(after["stats"]) <= cost(before) and (n > 0) == (cost(after["stats"]) < cost(before))
+        if n == 0:
+            assert all(np.array_equal(a, np.array(b)) for a, b in zip(tree0, scene.bvh()))
+        ref = oracle_scene_for(orc, scene, 1).render(cam, W, H, spp, depth)      # (1: the restatement imports the tree as it is now)
+        _assert_render_matches(after, ref, "scene %d after the profile call" % sid, True, scene.n_tris)
+    with pytest.raises(srt.SrtError):
+        srt.Renderer(0).order_children_by_profile(scene, 32, 32, 1, 4)      # no camera set on that context
+
+
 def _soup(srt, seed, n, spread=6.0, size=0.25):
     """n small random triangles in a box, 6 materials (lambertian, metallic, dielectric, emissive), sky background"""
     rng = np.random.default_rng(4000 + seed)

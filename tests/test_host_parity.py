@@ -170,6 +170,57 @@ def test_order_children_leaves_the_default_camera_alone(srt):
             assert np.array_equal(scene.bvh()[0], l1)
 
 
+def test_optimise_bvh_keeps_a_valid_cheaper_tree(srt):
+    """srt_scene_optimise_bvh (insertion-based topology optimisation after Bittner et al. 2013, for throughput-bound launches): the
+    same triangles, one per leaf, every internal box the exact union of its children's, a sum of internal-node areas (the SAH cost
+    of a one-triangle-per-leaf tree) that is not larger than the top-down tree's, the nearer child on the left at every node, the
+    same result for every viewpoint the tree was built for -- and srt_scene_build_bvh itself unchanged by it."""
+    def arrays(scene):
+        l, r, p, b = scene.bvh()
+        return np.array(l), np.array(r), np.array(p), np.array(b, dtype=np.float32).reshape(-1, 6)
+    def sah(p, b):
+        d = b[:, 1::2].astype(np.float64) - b[:, 0::2]
+        a = 2 * (d[:, 0] * d[:, 1] + d[:, 1] * d[:, 2] + d[:, 2] * d[:, 0])
+        return float(a[p < 0].sum())
+    plain = srt.Scene.builtin(srt.SCENE_RANDOM_SPHERES, 0).build_bvh(srt.BVH_SAH)
+    l0, r0, p0, b0 = arrays(plain)
+    tuned = srt.Scene.builtin(srt.SCENE_RANDOM_SPHERES, 0).build_bvh(srt.BVH_SAH)
+    assert all(np.array_equal(x, y) for x, y in zip(arrays(tuned), (l0, r0, p0, b0)))      # the builder is deterministic
+    tuned.optimise_bvh(0)
+    assert all(np.array_equal(x, y) for x, y in zip(arrays(tuned), (l0, r0, p0, b0)))      # 0 passes: untouched
+    tuned.optimise_bvh(3)
+    l1, r1, p1, b1 = arrays(tuned)
+    assert len(p1) == len(p0) == 2 * tuned.n_tris - 1
+    assert sorted(p1[p1 >= 0].tolist()) == list(range(tuned.n_tris))
+    inner = np.nonzero(p1 < 0)[0]
+    # (srt_scene_get_bvh numbers the nodes in depth-first pre-order: the left child follows its parent)
+    assert np.all(l1[inner] == inner + 1) and np.all(r1[inner] > l1[inner])
+    for lo in (0, 2, 4):
+        assert np.array_equal(b1[inner, lo], np.minimum(b1[l1[inner], lo], b1[r1[inner], lo]))
+        assert np.array_equal(b1[inner, lo + 1], np.maximum(b1[l1[inner], lo + 1], b1[r1[inner], lo + 1]))
+    assert sah(p1, b1) <= sah(p0, b0)
+    assert not np.array_equal(b1, b0)          # ... and it did change the tree
+    cam = tuned.default_camera(64, 64)
+    eye = np.array([cam.camera_center[0], cam.camera_center[1], cam.camera_center[2]], dtype=np.float64)
+    def dist2(bx, e):
+        lo, hi = bx[:, 0::2].astype(np.float64), bx[:, 1::2].astype(np.float64)
+        d = np.where(e < lo, lo - e, np.where(e > hi, e - hi, 0.0))
+        return (d * d).sum(axis=1)
+    assert np.all(dist2(b1[l1[inner]], eye) <= dist2(b1[r1[inner]], eye))
+    # (all but) converged after three passes; and the topology does not depend on the viewpoint the top-down tree was ordered for
+    again = srt.Scene.builtin(srt.SCENE_RANDOM_SPHERES, 0).build_bvh(srt.BVH_SAH).optimise_bvh(6)
+    assert sah(p1, b1) * (1 - 1e-5) <= sah(*arrays(again)[2:]) <= sah(p1, b1)
+    other = srt.Scene.builtin(srt.SCENE_RANDOM_SPHERES, 0).build_bvh(srt.BVH_SAH)
+    other.order_children((-7.0, 3.5, 11.0)); other.optimise_bvh(3)
+    lo_, ro_, po_, bo_ = arrays(other)
+    assert np.array_equal(np.sort(bo_, axis=0), np.sort(b1, axis=0))
+    e2 = np.array((-7.0, 3.5, 11.0))
+    io = np.nonzero(po_ < 0)[0]
+    assert np.all(dist2(bo_[lo_[io]], e2) <= dist2(bo_[ro_[io]], e2))
+    with pytest.raises(srt.SrtError):
+        srt.Scene.builtin(srt.SCENE_PRISM, 0).optimise_bvh(3)      # no tree built yet
+
+
 def test_order_children_for_a_viewpoint(srt, orc):
     """srt_scene_order_children: same topology / boxes / depth, every internal node's nearer child (to the eye) on the left; the
     tree stays a valid input for the oracle (which imports it) -- GPU/oracle parity on a re-ordered tree is covered by the GPU suite."""

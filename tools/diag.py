@@ -14,6 +14,9 @@ a = ap.parse_args()
 scene = srt.Scene.builtin(a.scene, 0).build_bvh(a.bvh, 1984)
 cam = scene.default_camera(a.width, a.height)
 r = srt.Renderer(0)
+r.upload_scene(scene)
+if a.bvh == 1 and os.environ.get("SRT_TOOL_NO_TUNING") != "1" and srt.pixels_per_lane(r, a.width, a.height, a.world) >= 6.0:
+    srt.tune_tree_for_throughput(r, scene, a.width, a.height, a.depth)      # the tree bench.py renders a throughput-bound launch with
 r.upload_scene(scene); r.set_camera(cam); r.set_partition(a.rank, a.world)
 res = {"tris": scene.n_tris, "nodes": scene.n_nodes, "depth": scene.bvh_depth}
 for count in (True, False):

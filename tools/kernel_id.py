@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Identity of the render kernel's machine code.
 
-Primary: sha256 of the BYTES of the production render kernels inside the gfx950 code object of a built libsrt_hip.so -- the
+Primary: sha256 of the BYTES (PC-relative literals zeroed, see position_independent) of the production render kernels inside the
+gfx950 code object of a built libsrt_hip.so -- the
 library that is actually loaded (cuda-spectral-ray-tracer_amd.binding.LIB_PATH, i.e. SRT_LIB_PATH when a variant build is being
 measured): the .hip_fatbin section holds clang offload bundles, each bundle a gfx950 ELF whose symbol table gives address and size
 of every kernel.  `code_hash(lib, narrow, all_cached)`.
@@ -57,9 +58,28 @@ def _elf_function_bytes(elf):
     return out
 
 
+def position_independent(code):
+    """The kernel's bytes with the PC-relative literals zeroed.  A kernel addresses the constant tables of its code object with
+    s_getpc_b64 sN ; s_add_u32 sN, sN, LITERAL ; s_addc_u32 sN+1, sN+1, LITERAL: the literals are distances inside the code object
+    and move whenever ANY other function of the translation unit changes size, although not one instruction of this kernel differs
+    (measured: three dwords per render kernel).  Zeroing them makes the hash a statement about the kernel's instructions alone."""
+    n = len(code) // 4
+    w = list(struct.unpack_from("<%dI" % n, code, 0))
+    for i in range(n - 2):
+        if (w[i] & 0xFF80FFFF) != 0xBE801C00:              # s_getpc_b64 sdst
+            continue
+        j = i + 1
+        if (w[j] & 0xFF80FF00) == 0x8000FF00:               # s_add_u32 sdst, ssrc0, literal
+            w[j + 1] = 0
+            j += 2
+            if j + 1 < n and (w[j] & 0xFF80FF00) == 0x8200FF00:      # s_addc_u32 sdst, ssrc0, literal
+                w[j + 1] = 0
+    return struct.pack("<%dI" % n, *w) + code[4 * n:]
+
+
 def code_hashes(lib=LIB):
-    """{(narrow, all_cached): sha256 of the kernel's machine code} for the production render kernels of a built library; {} when the
-    file is missing or holds no gfx950 code object with them"""
+    """{(narrow, all_cached): sha256 of the kernel's position-independent machine code} for the production render kernels of a built
+    library; {} when the file is missing or holds no gfx950 code object with them"""
     out = {}
     try:
         data = open(lib, "rb").read()
@@ -77,7 +97,7 @@ def code_hashes(lib=LIB):
                 for name, code in _elf_function_bytes(data[pos + off:pos + off + size]).items():
                     m = RENDER_SYM.match(name)
                     if m:
-                        out[(int(m.group(1)), int(m.group(2)))] = hashlib.sha256(code).hexdigest()
+                        out[(int(m.group(1)), int(m.group(2)))] = hashlib.sha256(position_independent(code)).hexdigest()
         pos = data.find(BUNDLE_MAGIC, pos + 1)
     return out
 

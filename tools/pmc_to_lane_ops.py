@@ -26,7 +26,7 @@ w, h, spp = [int(x) for x in re.search(r"(\d+)x(\d+), (\d+) spp", b["config"]["w
 rays = w * h * spp * b["rays_per_path"]
 wc = c["SQ_WAVE_CYCLES"]
 entry = {
-    "kernel": tag, "kernel_code_sha256": (b.get("roofline") or {}).get("kernel_code_sha256"), "kernel_isa_sha256": (b.get("roofline") or {}).get("kernel_isa_sha256"), "kernel_variant": (b.get("roofline") or {}).get("kernel"), "source": "tools/pmc_passes.sh: rocprofv3 --pmc <set> --kernel-trace, one counter set per run, render_kernel<0,...> dispatch, %dx%d, %d spp" % (w, h, spp),
+    "kernel": tag, "kernel_code_sha256": (b.get("roofline") or {}).get("kernel_code_sha256"), "kernel_isa_sha256": (b.get("roofline") or {}).get("kernel_isa_sha256"), "tree_sha256": (b.get("roofline") or {}).get("tree_sha256"), "kernel_variant": (b.get("roofline") or {}).get("kernel"), "source": "tools/pmc_passes.sh: rocprofv3 --pmc <set> --kernel-trace, one counter set per run, render_kernel<0,...> dispatch, %dx%d, %d spp" % (w, h, spp),
     "rays_in_pmc_launch": rays,
     "lane_ops_per_ray": c["SQ_THREAD_CYCLES_VALU"] / rays,
     "valu_wave_instr_per_ray": c["SQ_INSTS_VALU"] / rays, "salu_wave_instr_per_ray": c["SQ_INSTS_SALU"] / rays,

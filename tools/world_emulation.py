@@ -15,11 +15,23 @@ a = ap.parse_args()
 scene = srt.Scene.builtin(a.scene, 0).build_bvh(a.bvh, 1984)
 cam = scene.default_camera(a.width, a.height)
 r = srt.Renderer(0)
+# the trees bench.py renders with: the SAH builder's for chain-bound launches (fewer than 6 pixels per lane), tuned for throughput otherwise
+tuned = None
+def scene_for(world):
+    global tuned
+    r.upload_scene(scene)
+    if a.bvh != 1 or os.environ.get("SRT_TOOL_NO_TUNING") == "1" or srt.pixels_per_lane(r, a.width, a.height, world) < 6.0:
+        return scene
+    if tuned is None:
+        tuned = srt.Scene.builtin(a.scene, 0).build_bvh(a.bvh, 1984)
+        srt.tune_tree_for_throughput(r, tuned, a.width, a.height, a.depth)
+    return tuned
 r.upload_scene(scene); r.set_camera(cam)
 r.set_partition(0, 1); r.init_device_params(a.width, a.height, 8, a.depth, 1984); r.render_chunk(a.width, a.height); r.synchronize()   # warm-up
 out = {}
 for W in [int(x) for x in a.worlds.split(",")]:
     ms, reps = [], []
+    r.upload_scene(scene_for(W)); r.set_camera(cam)
     for rank in ([int(x) for x in a.ranks.split(',') if int(x) < W] if a.ranks else range(W)):
         r.set_partition(rank, W)
         best, every = 1e30, []
