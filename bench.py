@@ -567,12 +567,20 @@ def timed_frames(job, W, H, spp, depth, steps, warmup, label=""):
     return dict(elapsed=elapsed, total_rays=total_rays, rows=rows, kms=max(x[0] for x in rows), rays_rank0=rows[0][1])
 
 
-def lane_ops_entry(scene_id):
+def lane_ops_entry(scene_id, tree=None):
+    """the committed PMC entry of a scene: "scene_<id>", or -- when the run traverses another tree of the same scene (the builder's
+    tree of a chain-bound launch next to the throughput-tuned one) -- the entry "scene_<id>_*" that was taken on that tree"""
     for f in LANE_OPS_FILES:
         try:
-            e = json.load(open(f)).get("scene_%d" % scene_id)
+            doc = json.load(open(f))
         except Exception:      # noqa: BLE001
-            e = None
+            continue
+        e = doc.get("scene_%d" % scene_id)
+        if tree is not None and (e is None or e.get("tree_sha256") != tree):
+            for k, v in doc.items():
+                if k.startswith("scene_%d_" % scene_id) and isinstance(v, dict) and v.get("tree_sha256") == tree:
+                    e = v
+                    break
         if e is not None:
             return e, os.path.relpath(f, ROOT)
     return None, None
@@ -613,7 +621,7 @@ def kernel_tie(renderer, entry, lib_path, tree=None):
 
 def small_roofline(renderer, scene_id, rays_per_launch, kms, lib_path, tree=None):
     """frac_arch of a secondary workload: imported lane-ops per ray of ITS kernel variant / scene (hash-tied) x live rays / live kernel time"""
-    entry, entry_file = lane_ops_entry(scene_id)
+    entry, entry_file = lane_ops_entry(scene_id, tree)
     plan, variant, hashes, tie = kernel_tie(renderer, entry, lib_path, tree)
     out = {"kernel": variant, "tree_sha256": tree, "kernel_code_sha256": hashes["code_sha256"], "kernel_isa_sha256": hashes["isa_listing_sha256"], "frac_arch": None, "achieved_source": None}
     if entry is not None:
@@ -798,7 +806,7 @@ def main():
         rays_per_launch_rank0 = tf["rays_rank0"]
         b_ray = tc["b_ray"]
         # ---- roofline of the dominant kernel (render_kernel) on this rank -------------------------------------------
-        entry, entry_file = lane_ops_entry(args.scene)
+        entry, entry_file = lane_ops_entry(args.scene, scene_tree)
         plan, variant, hashes, tie = kernel_tie(job.root, entry, srt.binding.LIB_PATH, scene_tree)
         roof = {"bound": "valu-issue", "achieved": None, "peak": None, "unit": "G lane-op/s", "frac": None, "frac_arch": None, "traffic": None,
                 "peak_arch": ARCH_PEAK_GLANEOPS,
