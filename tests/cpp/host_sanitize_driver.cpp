@@ -40,6 +40,21 @@ static int exercise(srt_scene *s, int mode, size_t expect_tris) {
     CHECK(srt::flatten_scene(*s, g) == SRT_OK && g.n_records == f.n_records && g.stack_depth == f.stack_depth);
     srt_camera_data cam;
     CHECK(srt_scene_default_camera(s, 123, 77, &cam) == SRT_OK);
+    // the topology optimisation on every kind of tree (leaf root, two leaves, reference topology, 100k triangles): still one leaf
+    // per triangle, still a tree flatten_scene accepts, every reference in range
+    CHECK(srt_scene_optimise_bvh(s, 2) == SRT_OK);
+    CHECK(srt_scene_node_count(s) == nodes);
+    std::vector<int32_t> p2(nodes);
+    CHECK(srt_scene_get_bvh(s, l.data(), r.data(), p2.data(), boxes.data()) == SRT_OK);
+    std::vector<int> seen(n, 0);
+    for (size_t k = 0; k < nodes; k++)
+        if (p2[k] >= 0) { CHECK((size_t)p2[k] < n); seen[(size_t)p2[k]]++; }
+        else CHECK(l[k] > (int32_t)k && r[k] > (int32_t)k && (size_t)l[k] < nodes && (size_t)r[k] < nodes);
+    for (size_t k = 0; k < n; k++) CHECK(seen[k] == 1);
+    srt::FlatScene h;
+    CHECK(srt::flatten_scene(*s, h) == SRT_OK && h.n_records == f.n_records);
+    for (int k = 0; k < h.n_inner; k++)
+        for (int c = 0; c < 2; c++) { int32_t ref; memcpy(&ref, &h.nodes[16 * k + 12 + c], 4); CHECK(ref >= 0 && ref < h.n_records); }
     return 0;
 }
 
