@@ -373,13 +373,19 @@ def test_second_render_continues_rng_streams(srt, gpu, orc):
     assert not np.array_equal(first[1], second[1])
 
 
-def test_full_size_blocks_bit_exact(srt, gpu, orc):
+@pytest.mark.parametrize("tuned", [True, False], ids=["throughput-tuned tree (what bench.py's headline renders)", "the SAH builder's tree"])
+def test_full_size_blocks_bit_exact(srt, gpu, orc, tuned):
     """BASELINE's headline configuration at FULL size (random-spheres scene, 1920x1080, 1024 spp, depth 16) rendered on the
     GPU; a spread of the reference's 28x16-pixel blocks (top rows = sky, horizon, spheres, foreground) is re-rendered by
-    the oracle at full spp and compared bit for bit.  Same seeds (1984 + block-linear index), same tree."""
+    the oracle at full spp and compared bit for bit.  Same seeds (1984 + block-linear index), same tree -- the tree bench.py's
+    headline frame is measured on (srt.tune_tree_for_throughput: reinsertion + profiled child order) and the builder's."""
     import os
     W, H, spp, depth = 1920, 1080, 1024, 16
     scene = srt.Scene.builtin(srt.SCENE_RANDOM_SPHERES, 0).build_bvh(srt.BVH_SAH)
+    if tuned:
+        gpu.upload_scene(scene)
+        assert srt.pixels_per_lane(gpu, W, H, 1) >= 6.0
+        assert "nodes swapped" in srt.tune_tree_for_throughput(gpu, scene, W, H, depth)
     cam = scene.default_camera(W, H)
     gpu.upload_scene(scene); gpu.set_camera(cam); gpu.set_partition(0, 1)
     gpu.init_device_params(W, H, spp, depth, 1984)
@@ -418,6 +424,10 @@ def test_full_frame_full_spp_bit_exact(srt, gpu, orc):
     spp, depth = int(os.environ.get("SRT_LONG_SPP", str(spp))), 16
     bvh_mode = srt.BVH_REFERENCE if cfg == "4" else srt.BVH_SAH      # (the reference's scene on the reference builder's tree)
     scene = srt.Scene.builtin(sid, 0).build_bvh(bvh_mode, 1984)
+    if bvh_mode == srt.BVH_SAH and os.environ.get("SRT_LONG_TUNED", "1") == "1":      # the tree bench.py measures this frame on
+        gpu.upload_scene(scene)
+        if srt.pixels_per_lane(gpu, W, H, 1) >= 6.0:
+            print("tree: " + srt.tune_tree_for_throughput(gpu, scene, W, H, depth), file=sys.stderr, flush=True)
     cam = scene.default_camera(W, H)
     gpu.upload_scene(scene); gpu.set_camera(cam); gpu.set_partition(0, 1)
     gpu.init_device_params(W, H, spp, depth, 1984)
