@@ -16,6 +16,7 @@ first = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 gpu = srt.Renderer(0); gpu.set_gather_planes(9)
 bad = 0
+swapped = 0
 for seed in range(first, first + count):
     rng = np.random.default_rng(1000 + seed)
     n = int(rng.integers(3, 400))
@@ -45,6 +46,13 @@ for seed in range(first, first + count):
     W, H, spp, depth = int(rng.integers(9, 90)), int(rng.integers(9, 60)), int(rng.integers(1, 12)), int(rng.integers(1, 17))
     cam = srt.camera_init(W, H, float(rng.uniform(20, 90)), tuple(rng.uniform(-12, 12, 3)), tuple(rng.uniform(-2, 2, 3)),
                           defocus_angle=float(rng.choice([0.0, 0.0, 1.5])), focus_dist=float(rng.uniform(5, 15)))
+    if os.environ.get("FUZZ_TUNE") == "1" and n > 3:
+        # the tree tuning of DESIGN.md 5.4 on a random scene: reinsertion passes + child order from a probe frame of this very camera;
+        # the CPU restatement then imports the tree as it is (mode 1), whatever builder it came from
+        scene.optimise_bvh(int(rng.integers(1, 4)))
+        gpu.set_camera(cam)
+        swapped += gpu.order_children_by_profile(scene, W, H, max(spp, 2), depth, int(rng.integers(1, 4)))
+        mode = 1
     ref = oracle_scene_for(orc, scene, mode).render(cam, W, H, spp, depth)
     for counted in (True, False):
         out = srt.render_image(scene, cam, W, H, spp, depth, renderer=gpu, count_traversal=counted)
@@ -58,5 +66,5 @@ for seed in range(first, first + count):
             print("MISMATCH seed %d counted=%s (%d tris, %d mats, mode %d, %dx%d %d spp depth %d)" % (seed, counted, n, n_mats, mode, W, H, spp, depth), flush=True)
     if (seed - first) % 25 == 24:
         print("seed %d done, %d mismatches so far" % (seed, bad), flush=True)
-print("fuzz campaign: seeds %d..%d, both kernel builds, %d mismatches" % (first, first + count - 1, bad))
+print("fuzz campaign: seeds %d..%d, both kernel builds, %d mismatches%s" % (first, first + count - 1, bad, (" (trees tuned: %d nodes swapped by the profiled order in all)" % swapped) if os.environ.get("FUZZ_TUNE") == "1" else ""))
 sys.exit(1 if bad else 0)
