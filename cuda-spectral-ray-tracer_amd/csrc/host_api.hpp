@@ -133,6 +133,34 @@ public:
     int getYres() const { return yr; }
     size_t getWorldSize() const { return srt_scene_tri_count(s); }
     size_t getNumMaterials() const { return srt_scene_material_count(s); }
+    // Tree tuning for a THROUGHPUT-bound render of the whole image on n_gpus devices (no reference counterpart: the tree is an
+    // input of bvh::hit, bvh/bvh.cu:98-166): when a rank's launch has at least 6 pixels per persistent lane, the
+    // SAH tree is post-optimised by reinsertion (up to 8 192 triangles) and its child order is measured on one instrumented
+    // probe frame of the scene's camera at full size, 1 sample per pixel (srt_order_children_by_profile, which undoes itself when
+    // the probe frame did not get cheaper).  Launches with fewer pixels per lane are bound by their longest pixel and keep the
+    // tree as built.  Call before the renderer is created (it uploads the scene).  Returns what was done, for the log.
+    std::string tune_tree_for_throughput(uint bounce_limit, int device = 0, int n_gpus = 1) {
+        if (!world_inited) return "no scene";
+        srt_ctx *probe = nullptr;
+        if (srt_create(device, &probe) != SRT_OK) return std::string("no tuning: ") + srt_last_error(nullptr);
+        std::string what = "tree as built";
+        int waves = 0;
+        if (srt_upload_scene(probe, s) == SRT_OK && srt_launch_plan(probe, &waves, nullptr, nullptr, nullptr) == SRT_OK) {
+            const double lanes = (double)srt_ctx_cu_count(probe) * waves * 64.0;
+            const double per_lane = (double)xr * yr / (double)(n_gpus < 1 ? 1 : n_gpus) / (lanes > 0 ? lanes : 1.0);
+            if (per_lane >= 6.0) {
+                what = "";
+                if (srt_scene_tri_count(s) <= 8192 && srt_scene_optimise_bvh(s, 3) == SRT_OK) what = "3 reinsertion passes; ";
+                uint32_t swapped = 0;
+                if (srt_set_camera(probe, &cam_data) == SRT_OK &&
+                    srt_order_children_by_profile(probe, s, (uint32_t)xr, (uint32_t)yr, 1, bounce_limit, 16, &swapped) == SRT_OK)
+                    what += swapped ? "child order profiled: " + std::to_string(swapped) + " nodes swapped" : "builder's child order kept";
+                else what += std::string("child order not profiled: ") + srt_last_error(probe);
+            } else what = "tree as built (chain-bound launch: fewer than 6 pixels per lane)";
+        }
+        srt_destroy(probe);
+        return what;
+    }
 private:
     srt_scene *s = nullptr;
     srt_camera_data cam_data{};

@@ -62,6 +62,13 @@ int main(int argc, char **argv) {
     lc.add_entry("# primitives", sm.getWorldSize());
     lc.add_entry("# materials", sm.getNumMaterials());
 
+    if (pm.sah) {      // this build's own tree: tuned for throughput-bound renders; SRT_NO_TREE_TUNING=1 keeps it as built
+        const char *no = getenv("SRT_NO_TREE_TUNING");
+        const std::string tuned = (no && no[0] == '1') ? std::string("tree as built (SRT_NO_TREE_TUNING)") : sm.tune_tree_for_throughput(pm.bounce_limit, pm.gpus > 1 ? 0 : pm.gpu, pm.gpus > 1 ? pm.gpus : 1);
+        std::clog << "BVH: " << tuned << std::endl;
+        lc.add_entry("bvh tuning", tuned);
+    }
+
     frame_buffer fb((size_t)pm.xres * pm.yres);
     image_channels ch(fb);
     // the scene's own camera builder (scene.cu:259-320), evaluated by the library for this image size

@@ -119,6 +119,29 @@ def test_cli_driver_two_and_three_ranks_mock_transport(srt, tmp_path):
 
 
 @pytest.mark.gpu
+def test_cli_driver_tunes_its_own_tree_for_throughput_bound_renders(srt, tmp_path):
+    """srt_render --sah (this build's own tree): scene_manager::tune_tree_for_throughput (host_api.hpp) -- reinsertion + child order
+    from a probe frame when the render has at least 6 pixels per lane, the tree as built otherwise.  The tree is an input of the
+    traversal: the image of the tuned run equals the untuned run's except where two triangles tie exactly in t (a handful of
+    bytes at most), and a chain-bound render is byte-identical."""
+    exe = os.path.join(PKG, "srt_render")
+    def run(title, xres, env_extra):
+        p = subprocess.run([exe, "-s", "100", "--sah", "-xr", str(xres), "-ar", "16/9", "-ns", "2", "-bl", "8", "-t", title, "--save", "--no-show"],
+                           cwd=str(tmp_path), capture_output=True, timeout=300, env=dict(os.environ, **env_extra))
+        assert p.returncode == 0, p.stderr[-500:]
+        return (tmp_path / "renders" / (title + ".bmp")).read_bytes(), p.stderr.decode(errors="replace")
+    big_tuned, log_tuned = run("big_tuned", 1920, {})
+    big_plain, log_plain = run("big_plain", 1920, {"SRT_NO_TREE_TUNING": "1"})
+    assert "BVH: 3 reinsertion passes; child order profiled:" in log_tuned and "nodes swapped" in log_tuned
+    assert "BVH: tree as built (SRT_NO_TREE_TUNING)" in log_plain
+    a, b = np.frombuffer(big_tuned, np.uint8), np.frombuffer(big_plain, np.uint8)
+    assert a.size == b.size == 54 + 1920 * 1080 * 3 and int(np.count_nonzero(a != b)) <= 64
+    small_tuned, log_small = run("small_tuned", 320, {})
+    small_plain, _ = run("small_plain", 320, {"SRT_NO_TREE_TUNING": "1"})
+    assert "chain-bound launch" in log_small and small_tuned == small_plain
+
+
+@pytest.mark.gpu
 def test_cli_driver_reports_failure(srt, tmp_path):
     """A render that cannot run (device index that does not exist; more GPUs than the box has) must not exit 0 with a black
     image: the reference dies in checkCudaErrors -> exit(99) (utils/cuda_utility.cu:8-18), this driver returns non-zero."""
