@@ -201,8 +201,11 @@ int build_bvh_reference(srt_scene &s, uint64_t seed) {
 // Insertion-based optimisation of a finished tree (after Bittner, Hapala, Havran: "Fast insertion-based optimization of bounding
 // volume hierarchies", 2013): take a subtree out, let its sibling take the parent's place, and put it back where it adds the least
 // surface area to the tree -- found by a branch-and-bound search from the root over (area added to the ancestors) + (area of the new
-// parent).  The search space contains the position the subtree came from, so a step never makes the sum of the internal nodes'
-// areas (the SAH cost of a one-triangle-per-leaf tree) worse.  Nodes are processed in order of decreasing area, `passes` times.
+// parent).  The search space contains the position the subtree came from, so with plain areas a step never makes the sum of the
+// internal nodes' areas (the SAH cost of a one-triangle-per-leaf tree) worse; the objective used here weighs nodes with a leaf child
+// by the cost of a FRINGE visit (below), for which the bookkeeping of a step is local (the type changes at the place a subtree
+// leaves are not priced) -- a heuristic, judged by the measured records / triangle tests per ray.  Nodes are processed in order of
+// decreasing area, `passes` times.
 // Leaves stay one triangle each; only the topology above them changes.  The tree is an input of the traversal: results do not
 // depend on it (except where two triangles tie exactly in t, Q11 -- and the CPU checker walks the same tree).
 static void optimise_bvh_by_reinsertion(srt_scene &s, int passes) {
@@ -267,6 +270,14 @@ static void optimise_bvh_by_reinsertion(srt_scene &s, int passes) {
     };
     struct Cand { double induced; int32_t node; bool operator<(const Cand &o) const { return induced > o.induced; } };
     std::vector<Cand> heap;
+    // Not every node costs the same to visit: a node with a leaf child is a FRINGE record (box + triangle tests) and the kernel's
+    // instruction budget prices a FRINGE visit at 2.5 INNER visits (27 % of the vector instructions for 3.9 visits per ray against
+    // 36 % for 13.0).  So the objective is sum(area x visit cost), with cf for nodes that have a leaf child -- it
+    // pairs leaves up and turns leaf + subtree nodes into INNER ones where that is cheap: T 3.99 -> 3.95 triangle tests per ray at
+    // the same V on cfg 3's scene, another -1.3 % (SRT_BVH_FRINGE_WEIGHT overrides; 1 = plain surface area).
+    const double cf = getenv("SRT_BVH_FRINGE_WEIGHT") ? std::max(1.0, atof(getenv("SRT_BVH_FRINGE_WEIGHT"))) : 2.5;
+    auto is_leaf = [&](int32_t k) { return s.nodes[k].prim >= 0; };
+    auto wgt = [&](int32_t k) { return (!is_leaf(k) && (is_leaf(s.nodes[k].left) || is_leaf(s.nodes[k].right))) ? cf : 1.0; };
     std::vector<int32_t> todo(n);
     for (int pass = 0; pass < passes; pass++) {
         for (int32_t k = 0; k < n; k++) todo[k] = k;
@@ -286,14 +297,25 @@ static void optimise_bvh_by_reinsertion(srt_scene &s, int passes) {
             while (!heap.empty()) {
                 std::pop_heap(heap.begin(), heap.end());
                 const Cand c = heap.back(); heap.pop_back();
-                if (c.induced + a_n >= best_cost) break;      // every remaining position costs at least that
+                const int32_t gx = parent[c.node];
+                const double credit_max = cf > 1.0 && gx >= 0 ? (cf - 1.0) * area[gx] : 0.0;
+                if (c.induced + a_n - credit_max >= best_cost) break;      // every remaining position costs at least that
                 const BvhNode &x = s.nodes[c.node];
                 float u[6];
                 for (int a = 0; a < 3; a++) { u[2 * a] = fminf(x.box[2 * a], nb[2 * a]); u[2 * a + 1] = fmaxf(x.box[2 * a + 1], nb[2 * a + 1]); }
-                const double direct = area_of(u);
+                const double ua = area_of(u);
+                double direct = ua;
+                if (cf > 1.0) {
+                    direct = ua * ((is_leaf(c.node) || is_leaf(N)) ? cf : 1.0);
+                    // x's parent loses a leaf child when x is a leaf: it turns into an INNER record if its other child is internal
+                    if (gx >= 0 && is_leaf(c.node)) {
+                        const int32_t other = s.nodes[gx].left == c.node ? s.nodes[gx].right : s.nodes[gx].left;
+                        if (!is_leaf(other)) direct -= (cf - 1.0) * area[gx];
+                    }
+                }
                 if (c.induced + direct < best_cost) { best_cost = c.induced + direct; best = c.node; }
-                const double below = c.induced + direct - area[c.node];      // what the ancestors of a position below x pay
-                if (x.prim < 0 && below + a_n < best_cost) {
+                const double below = c.induced + (ua - area[c.node]) * (cf > 1.0 ? wgt(c.node) : 1.0);      // what the ancestors of a position below x pay
+                if (x.prim < 0 && below + a_n - (cf > 1.0 ? (cf - 1.0) * area[c.node] : 0.0) < best_cost) {
                     heap.push_back({below, x.left}); std::push_heap(heap.begin(), heap.end());
                     heap.push_back({below, x.right}); std::push_heap(heap.begin(), heap.end());
                 }
