@@ -39,7 +39,7 @@ class CameraData(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("paths", C.c_uint64), ("node_visits", C.c_uint64), ("tri_tests", C.c_uint64),
                 ("box_tests", C.c_uint64), ("util", C.c_uint64 * 9), ("reserved", C.c_uint64 * 2), ("shade", C.c_uint64 * 4),
-                ("waves", C.c_uint64 * 4)]
+                ("waves", C.c_uint64 * 4), ("hits", C.c_uint64)]
 
 
 class Calibration(C.Structure):
@@ -88,6 +88,8 @@ PROTOTYPES = {
     "srt_upload_scene": (_i, [_vp, _vp]),
     "srt_set_camera": (_i, [_vp, C.POINTER(CameraData)]),
     "srt_launch_plan": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
+    "srt_set_test_knobs": (_i, [_vp, _i, _i, _u32]),
+    "srt_get_test_knobs": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_u32), C.POINTER(_i)]),
     "srt_launch_lds_bytes": (_i, [_vp, C.POINTER(_sz)]),
     "srt_init_device_params": (_i, [_vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _u64]),
     "srt_set_partition": (_i, [_vp, _u32, _u32]),

@@ -17,6 +17,9 @@
 //  12 the same with 16 lanes enabled, CONTIGUOUS (lanes 0-15: four full quads)
 //  13 the same with 16 lanes enabled, ONE PER QUAD (every fourth lane)   -- does the texture-address unit skip empty quads?
 //  14 the same with 32 contiguous lanes                                   15 the same with 32 lanes, two per quad
+//  16 / 17 / 18  4 x buffer_load_dword / dwordx2 / dwordx3 at the same four offsets of the record, all 64 lanes -- does the cost of a
+//                vector-memory instruction in the CU's memory front end scale with its width?          19 / 20 / 21 the same, 16 lanes
+//  22 three dwordx4 + one dword (a 52-byte record), 16 lanes
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -24,7 +27,7 @@
 
 namespace srt {
 
-constexpr int kCalibKinds = 16;
+constexpr int kCalibKinds = 23;
 
 #define REP4(x) x x x x
 
@@ -53,7 +56,12 @@ __global__ __launch_bounds__(1024) void calib_kernel(uint32_t iters, float *sink
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4 *>(table), 0, (int)(n_records * 64u), 0x00020000);
     uint32_t rnd = (blockIdx.x * blockDim.x + tid) * 2654435761u + 12345u;
     u4v g0 = {0, 0, 0, 0}, g1 = g0, g2 = g0, g3 = g0;
-    if (KIND == 12) asm volatile("s_mov_b64 %0, exec\n s_mov_b64 exec, 0xffff" : "=s"(saved_exec));
+    typedef unsigned int u2v __attribute__((ext_vector_type(2)));
+    typedef unsigned int u3v __attribute__((ext_vector_type(3)));
+    unsigned int h0 = 0, h1 = 0, h2 = 0, h3 = 0;
+    u2v i0 = {0, 0}, i1 = i0, i2 = i0, i3 = i0;
+    u3v j0 = {0, 0, 0}, j1 = j0, j2 = j0, j3 = j0;
+    if (KIND == 12 || (KIND >= 19 && KIND <= 22)) asm volatile("s_mov_b64 %0, exec\n s_mov_b64 exec, 0xffff" : "=s"(saved_exec));
     if (KIND == 13) asm volatile("s_mov_b64 %0, exec\n s_mov_b32 exec_lo, 0x11111111\n s_mov_b32 exec_hi, 0x11111111" : "=s"(saved_exec));
     if (KIND == 14) asm volatile("s_mov_b64 %0, exec\n s_mov_b64 exec, 0xffffffff" : "=s"(saved_exec));
     if (KIND == 15) asm volatile("s_mov_b64 %0, exec\n s_mov_b32 exec_lo, 0x33333333\n s_mov_b32 exec_hi, 0x33333333" : "=s"(saved_exec));
@@ -108,6 +116,46 @@ __global__ __launch_bounds__(1024) void calib_kernel(uint32_t iters, float *sink
                              "s_waitcnt vmcnt(4)\n"
                              : "=&v"(g0), "=&v"(g1), "=&v"(g2), "=&v"(g3) : "v"(off), "s"(rsrc) : "memory");
             }
+        } else if (KIND == 16 || KIND == 19) {
+#pragma unroll
+            for (int rr = 0; rr < 8; rr++) {
+                rnd = rnd * 1664525u + 1013904223u;
+                const uint32_t off = ((rnd >> 7) % n_records) * 64u;
+                asm volatile("buffer_load_dword %0, %4, %5, 0 offen\n buffer_load_dword %1, %4, %5, 0 offen offset:16\n"
+                             "buffer_load_dword %2, %4, %5, 0 offen offset:32\n buffer_load_dword %3, %4, %5, 0 offen offset:48\n"
+                             "s_waitcnt vmcnt(4)\n"
+                             : "=&v"(h0), "=&v"(h1), "=&v"(h2), "=&v"(h3) : "v"(off), "s"(rsrc) : "memory");
+            }
+        } else if (KIND == 17 || KIND == 20) {
+#pragma unroll
+            for (int rr = 0; rr < 8; rr++) {
+                rnd = rnd * 1664525u + 1013904223u;
+                const uint32_t off = ((rnd >> 7) % n_records) * 64u;
+                asm volatile("buffer_load_dwordx2 %0, %4, %5, 0 offen\n buffer_load_dwordx2 %1, %4, %5, 0 offen offset:16\n"
+                             "buffer_load_dwordx2 %2, %4, %5, 0 offen offset:32\n buffer_load_dwordx2 %3, %4, %5, 0 offen offset:48\n"
+                             "s_waitcnt vmcnt(4)\n"
+                             : "=&v"(i0), "=&v"(i1), "=&v"(i2), "=&v"(i3) : "v"(off), "s"(rsrc) : "memory");
+            }
+        } else if (KIND == 18 || KIND == 21) {
+#pragma unroll
+            for (int rr = 0; rr < 8; rr++) {
+                rnd = rnd * 1664525u + 1013904223u;
+                const uint32_t off = ((rnd >> 7) % n_records) * 64u;
+                asm volatile("buffer_load_dwordx3 %0, %4, %5, 0 offen\n buffer_load_dwordx3 %1, %4, %5, 0 offen offset:16\n"
+                             "buffer_load_dwordx3 %2, %4, %5, 0 offen offset:32\n buffer_load_dwordx3 %3, %4, %5, 0 offen offset:48\n"
+                             "s_waitcnt vmcnt(4)\n"
+                             : "=&v"(j0), "=&v"(j1), "=&v"(j2), "=&v"(j3) : "v"(off), "s"(rsrc) : "memory");
+            }
+        } else if (KIND == 22) {
+#pragma unroll
+            for (int rr = 0; rr < 8; rr++) {
+                rnd = rnd * 1664525u + 1013904223u;
+                const uint32_t off = ((rnd >> 7) % n_records) * 64u;
+                asm volatile("buffer_load_dwordx4 %0, %4, %5, 0 offen\n buffer_load_dwordx4 %1, %4, %5, 0 offen offset:16\n"
+                             "buffer_load_dwordx4 %2, %4, %5, 0 offen offset:32\n buffer_load_dword %3, %4, %5, 0 offen offset:48\n"
+                             "s_waitcnt vmcnt(4)\n"
+                             : "=&v"(g0), "=&v"(g1), "=&v"(g2), "=&v"(h3) : "v"(off), "s"(rsrc) : "memory");
+            }
         } else if (KIND == 9) {
             REP4(asm volatile("v_max3_f32 %0, %0, %8, %1\n v_max3_f32 %1, %1, %8, %2\n v_max3_f32 %2, %2, %8, %3\n v_max3_f32 %3, %3, %8, %4\n"
                               "v_max3_f32 %4, %4, %8, %5\n v_max3_f32 %5, %5, %8, %6\n v_max3_f32 %6, %6, %8, %7\n v_max3_f32 %7, %7, %8, %0\n"
@@ -119,12 +167,13 @@ __global__ __launch_bounds__(1024) void calib_kernel(uint32_t iters, float *sink
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
     __builtin_amdgcn_sched_barrier(0);
     if (KIND >= 11) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (KIND == 10 || (KIND >= 12 && KIND <= 15)) asm volatile("s_mov_b64 exec, %0" ::"s"(saved_exec));
+    if (KIND == 10 || (KIND >= 12 && KIND <= 15) || (KIND >= 19 && KIND <= 22)) asm volatile("s_mov_b64 exec, %0" ::"s"(saved_exec));
     const uint32_t gwave = (blockIdx.x * blockDim.x + tid) >> 6;
     if ((tid & 63u) == 0u) cycles[gwave] = t1 - t0;
     // keep every accumulator alive
     float acc = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + p0.x + p1.y + p2.x + p3.y + p4.x + p5.y + p6.x + p7.y +
-                (float)(s0 + s1 + s2 + s3 + s4 + s5 + s6 + s7) + (float)(g0.x + g1.y + g2.z + g3.w);
+                (float)(s0 + s1 + s2 + s3 + s4 + s5 + s6 + s7) + (float)(g0.x + g1.y + g2.z + g3.w) +
+                (float)(h0 + h1 + h2 + h3 + i0.x + i1.y + i2.x + i3.y + j0.x + j1.y + j2.z + j3.x);
     if (acc == 12345.678f) sink[tid] = acc;
 }
 
@@ -154,6 +203,13 @@ hipError_t launch_calib(int kind, uint32_t n_blocks, uint32_t threads, uint32_t 
     case 13: return run_kind<13>(n_blocks, threads, iters, sink, cycles, table, n_records, st);
     case 14: return run_kind<14>(n_blocks, threads, iters, sink, cycles, table, n_records, st);
     case 15: return run_kind<15>(n_blocks, threads, iters, sink, cycles, table, n_records, st);
+    case 16: return run_kind<16>(n_blocks, threads, iters, sink, cycles, table, n_records, st);
+    case 17: return run_kind<17>(n_blocks, threads, iters, sink, cycles, table, n_records, st);
+    case 18: return run_kind<18>(n_blocks, threads, iters, sink, cycles, table, n_records, st);
+    case 19: return run_kind<19>(n_blocks, threads, iters, sink, cycles, table, n_records, st);
+    case 20: return run_kind<20>(n_blocks, threads, iters, sink, cycles, table, n_records, st);
+    case 21: return run_kind<21>(n_blocks, threads, iters, sink, cycles, table, n_records, st);
+    case 22: return run_kind<22>(n_blocks, threads, iters, sink, cycles, table, n_records, st);
     default: return hipErrorInvalidValue;
     }
 }

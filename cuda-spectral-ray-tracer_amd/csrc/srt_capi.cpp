@@ -56,7 +56,11 @@ struct srt_ctx {
     // L2 (an inner step then costs about twice as much, so the other two kinds weigh twice as much relative to it);
     // measured plateaus: profiles/r02/knob_sweeps.txt.  0 = not set by the environment.
     uint32_t score_shade = 0, score_fringe = 0;        // env SRT_SCORE_SHADE / SRT_SCORE_FRINGE
-    uint32_t debug_lane_limit = 0;                     // env SRT_DEBUG_LANE_LIMIT (experiments: partial tiles)
+    uint32_t debug_lane_limit = 0;                     // test knob (experiments: partial tiles)
+    // Test knobs (srt_set_test_knobs; from the environment -- SRT_WIDE_REFS, SRT_LDS_CACHE_MAX, SRT_DEBUG_LANE_LIMIT -- only when
+    // SRT_TEST_KNOBS=1, read once here at srt_create): a stray variable in a user's shell cannot change the kernel variant that runs.
+    PlanKnobs knobs;
+    bool knobs_from_env = false;
     uint32_t split_load_pct = 200;                    // env SRT_SPLIT_LOAD: load factor (%) of the capacity constraint in order_tiles_kernel's split policy (0 = never split)
     uint32_t probe_spp = 2;                            // samples of the cost probe (env SRT_PROBE_SPP, 0 = no ordering)
     // queue order: tile cost moved this % towards 64 x its most expensive pixel (order_tiles_kernel).  -1 = automatic: 100 when the
@@ -170,7 +174,11 @@ int srt_create(int device, srt_ctx **out) {
     if (const char *ev = getenv("SRT_PROBE_SPP")) c->probe_spp = (uint32_t)std::max(0, atoi(ev));
     if (const char *ev = getenv("SRT_SCORE_SHADE")) c->score_shade = (uint32_t)std::max(1, atoi(ev));
     if (const char *ev = getenv("SRT_SCORE_FRINGE")) c->score_fringe = (uint32_t)std::max(1, atoi(ev));   // 0 would starve fringe lanes
-    if (const char *ev = getenv("SRT_DEBUG_LANE_LIMIT")) c->debug_lane_limit = (uint32_t)std::max(0, atoi(ev));
+    if (const char *tk = getenv("SRT_TEST_KNOBS")) if (atoi(tk) == 1) {
+        if (const char *ev = getenv("SRT_DEBUG_LANE_LIMIT")) { c->debug_lane_limit = (uint32_t)std::max(0, atoi(ev)); c->knobs_from_env = true; }
+        if (const char *ev = getenv("SRT_WIDE_REFS")) { c->knobs.wide_refs = atoi(ev) != 0; c->knobs_from_env = true; }
+        if (const char *ev = getenv("SRT_LDS_CACHE_MAX")) { c->knobs.lds_cache_max = std::max(0, atoi(ev)); c->knobs_from_env = true; }
+    }
     if (const char *ev = getenv("SRT_SPLIT_LOAD")) c->split_load_pct = (uint32_t)std::max(0, atoi(ev));
     if (const char *ev = getenv("SRT_ORDER_MAX_PCT")) c->order_max_pct = std::min(400, std::max(-1, atoi(ev)));
     {
@@ -214,14 +222,14 @@ int srt_upload_scene(srt_ctx *c, const srt_scene *s) {
     FlatScene f;
     int rc = flatten_scene(*s, f);
     if (rc != SRT_OK) return fail(c, rc, global_error());
-    if (render_lds_bytes(f.stack_depth, 1, 0, f.n_records) > 64 * 1024) return fail(c, SRT_ERR_BVH, "srt_upload_scene: BVH too deep for the LDS traversal stack");
+    if (render_lds_bytes(f.stack_depth, 1, 0, f.n_records, c->knobs) > 64 * 1024) return fail(c, SRT_ERR_BVH, "srt_upload_scene: BVH too deep for the LDS traversal stack");
     if ((rc = upload(c, &c->d_nodes, f.nodes)) != SRT_OK) return rc;
     {
         // FRINGE records are 96 B.  Packed, every second one straddles two 128-byte cache lines; when the tree is too large for
         // LDS every visit is an L2 round trip and a record that lies in ONE line halves the lines a FRINGE visit pulls through the
-        // CU's small L1: such trees get their fringe records padded to a 128-byte stride (SRT_FRINGE_STRIDE = 96 | 128 overrides).
+        // CU's small L1: SRT_FRINGE_STRIDE=128 pads such trees' records to a 128-byte stride (measured -1.4 % on cfg 5's scene, kept as a knob).
         LaunchPlan plan;
-        render_launch_plan(f.stack_depth, f.n_records, f.n_inner, plan);
+        render_launch_plan(f.stack_depth, f.n_records, f.n_inner, c->knobs, plan);
         uint32_t stride = plan.all_cached ? 96u : kFringeStrideL2;
         if (const char *ev = getenv("SRT_FRINGE_STRIDE")) stride = (atoi(ev) == 128 && !plan.all_cached) ? 128u : 96u;
         if ((uint64_t)(f.n_records - f.n_inner + 1) * stride >= (1ull << 31)) stride = 96u;
@@ -255,19 +263,37 @@ int srt_set_camera(srt_ctx *c, const srt_camera_data *cam) {
 int srt_launch_plan(const srt_ctx *c, int *waves_per_cu, int *n_cached, int *all_cached, int *narrow_refs) {
     if (!c || !c->scene_ready) return fail(nullptr, SRT_ERR_INVALID, "srt_launch_plan: no scene uploaded");
     LaunchPlan plan;
-    render_launch_plan(c->stack_depth, c->n_records, c->n_inner, plan);
+    render_launch_plan(c->stack_depth, c->n_records, c->n_inner, c->knobs, plan);
     if (waves_per_cu) *waves_per_cu = plan.waves_per_cu;
     if (n_cached) *n_cached = plan.n_cached;
     if (all_cached) *all_cached = plan.all_cached ? 1 : 0;
-    if (narrow_refs) *narrow_refs = render_narrow_refs(c->n_records) ? 1 : 0;
+    if (narrow_refs) *narrow_refs = render_narrow_refs(c->n_records, c->knobs) ? 1 : 0;
     return SRT_OK;
 }
 
 int srt_launch_lds_bytes(const srt_ctx *c, size_t *bytes) {
     if (!c || !c->scene_ready || !bytes) return fail(nullptr, SRT_ERR_INVALID, "srt_launch_lds_bytes: no scene uploaded / null argument");
     LaunchPlan plan;
-    render_launch_plan(c->stack_depth, c->n_records, c->n_inner, plan);
-    *bytes = render_lds_bytes(c->stack_depth, plan.waves_per_block, plan.n_cached, c->n_records);
+    render_launch_plan(c->stack_depth, c->n_records, c->n_inner, c->knobs, plan);
+    *bytes = render_lds_bytes(c->stack_depth, plan.waves_per_block, plan.n_cached, c->n_records, c->knobs);
+    return SRT_OK;
+}
+
+// Test knobs of a context: wide_refs != 0 sends small trees through the 32-bit-reference kernel variants, lds_cache_max >= 0 caps the
+// inner records kept in LDS (0 = every inner record from L2), lane_limit > 0 renders only the first lane_limit pixels of every tile.
+// -1 / 0 / 0 restores the defaults.  A scene uploaded before the call must be uploaded again (the FRINGE stride follows the plan).
+int srt_set_test_knobs(srt_ctx *c, int wide_refs, int lds_cache_max, uint32_t lane_limit) {
+    if (!c || lds_cache_max < -1 || lane_limit > 64) return fail(c, SRT_ERR_INVALID, "srt_set_test_knobs: bad argument");
+    c->knobs.wide_refs = wide_refs != 0; c->knobs.lds_cache_max = lds_cache_max; c->debug_lane_limit = lane_limit;
+    c->scene_ready = false;      // the upload's FRINGE stride and the plan must be made with the same knobs
+    return SRT_OK;
+}
+int srt_get_test_knobs(const srt_ctx *c, int *wide_refs, int *lds_cache_max, uint32_t *lane_limit, int *from_env) {
+    if (!c) return fail(nullptr, SRT_ERR_INVALID, "srt_get_test_knobs: null ctx");
+    if (wide_refs) *wide_refs = c->knobs.wide_refs ? 1 : 0;
+    if (lds_cache_max) *lds_cache_max = c->knobs.lds_cache_max;
+    if (lane_limit) *lane_limit = c->debug_lane_limit;
+    if (from_env) *from_env = c->knobs_from_env ? 1 : 0;
     return SRT_OK;
 }
 
@@ -311,6 +337,8 @@ int srt_set_partition(srt_ctx *c, uint32_t rank, uint32_t world) {
     return SRT_OK;
 }
 
+uint32_t srt_internal_gather_planes(const srt_ctx *c) { return c ? c->gather_planes : 0u; }
+
 int srt_set_gather_planes(srt_ctx *c, uint32_t planes) {
     if (!c || (planes != 3 && planes != 9)) return fail(c, SRT_ERR_INVALID, "srt_set_gather_planes: planes must be 3 or 9");
     c->gather_planes = planes;
@@ -351,7 +379,7 @@ int srt_render_chunk(srt_ctx *c, uint32_t width, uint32_t height, uint32_t offx,
     p.pixel_counter = (uint32_t *)(c->d_counters + kCounters);
     p.waves_per_cu_override = c->waves_per_cu;
     LaunchPlan plan;
-    render_launch_plan(c->stack_depth, c->n_records, c->n_inner, plan);
+    render_launch_plan(c->stack_depth, c->n_records, c->n_inner, c->knobs, plan);
     {
         const bool all_cached = plan.all_cached;
         // (inner records that come from L2 make an INNER visit ~2x as expensive, so shading and FRINGE visits weigh more:
@@ -381,7 +409,7 @@ int srt_render_chunk(srt_ctx *c, uint32_t width, uint32_t height, uint32_t offx,
         RenderParams pp = p;
         pp.spp = c->probe_spp; pp.tile_cost = c->d_tile_cost;
         RoctxRange range_probe("srt cost probe + pixel queue");
-        HIP_TRY(c, launch_render(pp, (uint32_t)c->n_cu, 2, st));
+        HIP_TRY(c, launch_render(pp, c->knobs, (uint32_t)c->n_cu, 2, st));
         const uint32_t split_pct = c->split_load_pct;
         const uint32_t n_waves_plan = (uint32_t)c->n_cu * (uint32_t)plan.waves_per_cu;
         const uint32_t order_pct = c->order_max_pct >= 0 ? (uint32_t)c->order_max_pct : ((!plan.all_cached && (uint64_t)c->tiles_local < 6ull * n_waves_plan) ? 100u : 0u);
@@ -394,26 +422,24 @@ int srt_render_chunk(srt_ctx *c, uint32_t width, uint32_t height, uint32_t offx,
     }
     if (c->count_traversal) {
         const uint32_t n_waves = (uint32_t)c->n_cu * (uint32_t)plan.waves_per_cu;
+        // layout of the debug buffer: [OrderProfile header][4 words per wave]: the header sits at a FIXED place, so the kernel finds it
+        // whatever number of waves the launcher ends up starting
         if (n_waves > c->wave_debug_waves) {
             if (c->d_wave_debug) { (void)hipFree(c->d_wave_debug); c->d_wave_debug = nullptr; c->wave_debug_waves = 0; }
-            HIP_TRY(c, hipMalloc((void **)&c->d_wave_debug, (size_t)n_waves * 4 * sizeof(uint32_t) + sizeof(OrderProfile)));      // (+ the profile header, srt_internal.h)
+            HIP_TRY(c, hipMalloc((void **)&c->d_wave_debug, sizeof(OrderProfile) + (size_t)n_waves * 4 * sizeof(uint32_t)));
             c->wave_debug_waves = n_waves;
         }
-        HIP_TRY(c, hipMemsetAsync(c->d_wave_debug, 0, (size_t)c->wave_debug_waves * 4 * sizeof(uint32_t) + sizeof(OrderProfile), st));
+        HIP_TRY(c, hipMemsetAsync(c->d_wave_debug, 0, sizeof(OrderProfile) + (size_t)c->wave_debug_waves * 4 * sizeof(uint32_t), st));
         p.wave_debug = c->d_wave_debug;
-        {
-            // the kernel looks for the header behind the words of the waves it was LAUNCHED with
-            uint32_t launched = std::min<uint32_t>(n_waves, p.queue_rows_bound);
-            const uint32_t wpb = (c->waves_per_cu > 0 && c->waves_per_cu < 16 && plan.waves_per_block == 16) ? c->waves_per_cu : (uint32_t)plan.waves_per_block;      // (as launch_render_cached)
-            if (wpb != (uint32_t)plan.waves_per_block) launched = std::min<uint32_t>((uint32_t)c->n_cu * wpb, p.queue_rows_bound);
-            launched = (launched + wpb - 1) / wpb * wpb;
-            if (c->order_profile.magic == kOrderProfileMagic && launched <= c->wave_debug_waves)
-                HIP_TRY(c, hipMemcpyAsync(c->d_wave_debug + 4 * (size_t)launched, &c->order_profile, sizeof(OrderProfile), hipMemcpyHostToDevice, st));
-        }
+        if (c->order_profile.magic == kOrderProfileMagic)
+            HIP_TRY(c, hipMemcpyAsync(c->d_wave_debug, &c->order_profile, sizeof(OrderProfile), hipMemcpyHostToDevice, st));
     }
     RoctxRange range_render("srt render_kernel");
     HIP_TRY(c, hipEventRecord(c->ev0, st));     // ev0..ev1 bracket the render kernel alone (roofline.achieved)
-    HIP_TRY(c, launch_render(p, (uint32_t)c->n_cu, c->count_traversal ? 1 : 0, st));
+    uint32_t waves_launched = 0;
+    HIP_TRY(c, launch_render(p, c->knobs, (uint32_t)c->n_cu, c->count_traversal ? 1 : 0, st, &waves_launched));
+    if (c->count_traversal && waves_launched > c->wave_debug_waves)
+        return fail(c, SRT_ERR_HIP, "srt_render_chunk: the launch started more waves than the debug buffer holds (launch plan and launcher disagree)");
     HIP_TRY(c, hipEventRecord(c->ev1, st));
     c->timed = true;
     c->last_paths = 0;   // filled by srt_get_stats from the tile ownership
@@ -535,12 +561,15 @@ int srt_get_stats(srt_ctx *c, srt_stats *out) {
     HIP_TRY(c, hipDeviceSynchronize());
     unsigned long long h[kCounters];
     HIP_TRY(c, hipMemcpy(h, c->d_counters, sizeof(h), hipMemcpyDeviceToHost));
+    if (h[23] != 0)      // instrumented launches: render_kernel S3's invariant (a wave's first fetch is made by all 64 lanes)
+        return fail(c, SRT_ERR_HIP, "srt_get_stats: a wave made a partial first fetch from the pixel queue: its assigned first row was not rendered");
     memset(out, 0, sizeof(*out));
     out->rays = h[0]; out->node_visits = h[1]; out->tri_tests = h[2]; out->box_tests = h[3];
     for (int k = 0; k < 9; k++) out->util[k] = h[4 + k];
     out->reserved[0] = h[13]; out->reserved[1] = h[14];
     for (int k = 0; k < 4; k++) out->shade[k] = h[15 + k];
     for (int k = 0; k < 4; k++) out->waves[k] = h[19 + k];   // instrumented: waves, sum / max of their life times, drain time
+    out->hits = h[24];
     // paths = spp * pixels owned by this rank
     uint64_t pixels = 0;
     for (uint32_t t = c->rank; t < c->n_tiles; t += c->world) {
@@ -557,7 +586,7 @@ int srt_get_wave_debug(srt_ctx *c, uint32_t *out, size_t n_waves) {
     if (!c || !out || !c->d_wave_debug || n_waves > c->wave_debug_waves) return fail(c, SRT_ERR_INVALID, "srt_get_wave_debug: no instrumented launch yet / bad size");
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipDeviceSynchronize());
-    HIP_TRY(c, hipMemcpy(out, c->d_wave_debug, n_waves * 4 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(out, reinterpret_cast<const char *>(c->d_wave_debug) + sizeof(OrderProfile), n_waves * 4 * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return SRT_OK;
 }
 
@@ -631,6 +660,13 @@ int srt_order_children_by_profile(srt_ctx *c, srt_scene *s, uint32_t width, uint
     std::vector<uint32_t> cnt(2 * n_nodes, 0u);
     if (rc == SRT_OK) { e = hipMemcpy(cnt.data(), d_cnt, cnt.size() * sizeof(uint32_t), hipMemcpyDeviceToHost); if (e != hipSuccess) rc = hip_fail(c, e, "srt_order_children_by_profile: read back"); }
     if (rc != SRT_OK) { release(); return rc; }
+    {
+        // a collecting launch that recorded nothing (header not seen by the kernel, or a probe frame without a single hit) must not read
+        // as "the order was already the cheapest"
+        unsigned long long samples = 0;
+        for (uint32_t v : cnt) samples += v;
+        if (samples == 0) { release(); return fail(c, SRT_ERR_INVALID, "srt_order_children_by_profile: the probe frame recorded no samples (no closest hit with the sibling's box beyond it)"); }
+    }
     const uint32_t *won = cnt.data();      // [node * 2 + side]: hits under that child with the sibling's box beyond the hit
     std::vector<uint32_t> swapped_nodes;
     for (size_t k = 0; k < n_nodes; k++) {

@@ -107,10 +107,10 @@ struct srt_comm {
     float *d_gathered = nullptr;       // on rank 0's device: world * tiles_padded * 9 * 64 floats, rank-major
     size_t gathered_capacity = 0;
     uint32_t gather_planes = 3;        // 3: the quantised framebuffer only (12 B / pixel); 9: + the parity planes
-    // one process per GPU only: the ranks set their plane count independently, and ncclGather with different counts hangs or
-    // corrupts.  The first frame after the count (or the communicator) changed exchanges the counts (one 4-byte all-gather) and
-    // every rank fails with the same message when they differ.
-    bool planes_agreed = false;
+    // one process per GPU only: the ranks set their plane count independently (srt_comm_set_gather_planes, or srt_set_gather_planes on
+    // the caller-owned context), and ncclGather with different counts hangs or corrupts.  EVERY frame of such a communicator therefore
+    // starts with the same collective on every rank -- a 4-byte all-gather of the count the rank's context will really use -- and every
+    // rank fails with the same message when they differ; no rank ever enters ncclGather alone.
     uint32_t *d_agree = nullptr;       // world words on this rank's device
     std::vector<hipEvent_t> ev_g0, ev_g1;   // per local context: around the gather (+ scatter on rank 0) of the last frame
     bool gather_timed = false;
@@ -163,7 +163,6 @@ int srt_comm_available(void) {
 int srt_comm_set_gather_planes(srt_comm *c, uint32_t planes) {
     if (!c || (planes != 3 && planes != 9)) return cfail(c, SRT_ERR_INVALID, "srt_comm_set_gather_planes: planes must be 3 or 9");
     for (srt_ctx *x : c->ctx) { int rc = srt_set_gather_planes(x, planes); if (rc != SRT_OK) return cfail(c, rc, srt_last_error(x)); }
-    if (planes != c->gather_planes && !c->owns_ctx) c->planes_agreed = false;      // (srt_comm_init_all: this call sets every rank's count)
     c->gather_planes = planes;
     return SRT_OK;
 }
@@ -196,17 +195,16 @@ int srt_comm_init_all(const int *devices, int n, srt_comm **out) {
     *out = nullptr;
     RcclApi &R = rccl();
     if (!R.handle) return cfail(nullptr, SRT_ERR_UNSUPPORTED, "srt_comm_init_all: " + R.error);
-    // One rank per GPU.  Test hook: SRT_COMM_TEST_SAME_DEVICE=1 lets several ranks share a device, and is honoured ONLY when the
-    // loaded transport identifies itself as the test transport (tests/cpp/mock_rccl.cpp exports srt_mock_rccl_marker; loaded
+    // One rank per GPU.  Test hook: SRT_COMM_TEST_SAME_DEVICE=1 (with SRT_TEST_KNOBS=1) lets several ranks share a device, and is honoured
+    // ONLY when the loaded transport identifies itself as the test transport (tests/cpp/mock_rccl.cpp exports srt_mock_rccl_marker; loaded
     // through SRT_RCCL_LIB) -- a duplicate device never reaches the real ncclCommInitAll.
-    const char *same = getenv("SRT_COMM_TEST_SAME_DEVICE");
-    const bool allow_same = same && same[0] == '1' && R.test_transport;
+    const char *same = getenv("SRT_COMM_TEST_SAME_DEVICE"), *knobs = getenv("SRT_TEST_KNOBS");
+    const bool allow_same = same && same[0] == '1' && knobs && atoi(knobs) == 1 && R.test_transport;
     for (int i = 0; i < n && !allow_same; i++)
         for (int j = 0; j < i; j++)
             if (devices[i] == devices[j]) return cfail(nullptr, SRT_ERR_INVALID, "srt_comm_init_all: a device is listed twice (one rank per GPU)");
     srt_comm *c = new srt_comm();
     c->world = (uint32_t)n; c->owns_ctx = true; c->root_local = 0;
-    c->planes_agreed = true;           // one process sets the count of every rank (srt_comm_set_gather_planes): agreed by construction
     c->ctx.assign(n, nullptr); c->rank.resize(n); c->nccl.assign(n, nullptr); c->stream.assign(n, nullptr);
     c->ev_g0.assign(n, nullptr); c->ev_g1.assign(n, nullptr);
     for (int i = 0; i < n; i++) {
@@ -279,6 +277,24 @@ int srt_render_frame_multi(srt_comm *c, uint32_t width, uint32_t height, uint32_
     if (!c) return cfail(c, SRT_ERR_INVALID, "srt_render_frame_multi: null comm");
     RcclApi &R = rccl();
     const size_t n_local = c->ctx.size();
+    if (c->world > 1 && !c->owns_ctx) {
+        // process-per-GPU communicator: agree on the exchange unit BEFORE anything of this frame is enqueued (see srt_comm::d_agree).
+        // The count is the one the context's launch and srt_tile_buffer will use, whichever call set it.
+        COMM_HIP(c, hipSetDevice(device_of(c->ctx[0])));
+        if (!c->d_agree) COMM_HIP(c, hipMalloc((void **)&c->d_agree, (size_t)(c->world + 1) * sizeof(uint32_t)));
+        const uint32_t mine = srt_internal_gather_planes(c->ctx[0]);
+        COMM_HIP(c, hipMemcpyAsync(c->d_agree + c->world, &mine, sizeof(mine), hipMemcpyHostToDevice, c->stream[0]));
+        COMM_NCCL(c, R.AllGather(c->d_agree + c->world, c->d_agree, 1, ncclUint32, c->nccl[0], c->stream[0]));
+        std::vector<uint32_t> all(c->world);
+        COMM_HIP(c, hipMemcpyAsync(all.data(), c->d_agree, c->world * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream[0]));
+        COMM_HIP(c, hipStreamSynchronize(c->stream[0]));
+        for (uint32_t r = 0; r < c->world; r++)
+            if (all[r] != all[0])
+                return cfail(c, SRT_ERR_INVALID, "srt_render_frame_multi: the ranks disagree on the exchange unit (rank 0 gathers " + std::to_string(all[0]) +
+                                                     " planes, rank " + std::to_string(r) + " " + std::to_string(all[r]) + ", this rank " + std::to_string(mine) +
+                                                     "): set the same value with srt_comm_set_gather_planes / srt_set_gather_planes on every rank");
+        c->gather_planes = mine;
+    }
     for (size_t i = 0; i < n_local; i++) {
         int rc = srt_render_chunk(c->ctx[i], width, height, offx, offy, c->stream[i]);
         if (rc != SRT_OK) return cfail(c, rc, srt_last_error(c->ctx[i]));
@@ -290,23 +306,6 @@ int srt_render_frame_multi(srt_comm *c, uint32_t width, uint32_t height, uint32_
     if (c->world == 1) {
         rc = srt_scatter_tiles(c->ctx[0], nullptr, c->stream[0]);
         return rc == SRT_OK ? SRT_OK : cfail(c, rc, srt_last_error(c->ctx[0]));
-    }
-    if (!c->planes_agreed) {
-        // (process-per-GPU communicators only, once per change of the plane count: see srt_comm::planes_agreed)
-        COMM_HIP(c, hipSetDevice(device_of(c->ctx[0])));
-        if (!c->d_agree) COMM_HIP(c, hipMalloc((void **)&c->d_agree, (size_t)(c->world + 1) * sizeof(uint32_t)));
-        const uint32_t mine = c->gather_planes;
-        COMM_HIP(c, hipMemcpyAsync(c->d_agree + c->world, &mine, sizeof(mine), hipMemcpyHostToDevice, c->stream[0]));
-        COMM_NCCL(c, R.AllGather(c->d_agree + c->world, c->d_agree, 1, ncclUint32, c->nccl[0], c->stream[0]));
-        std::vector<uint32_t> all(c->world);
-        COMM_HIP(c, hipMemcpyAsync(all.data(), c->d_agree, c->world * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream[0]));
-        COMM_HIP(c, hipStreamSynchronize(c->stream[0]));
-        for (uint32_t r = 0; r < c->world; r++)
-            if (all[r] != mine)
-                return cfail(c, SRT_ERR_INVALID, "srt_render_frame_multi: the ranks disagree on the exchange unit (rank " + std::to_string(r) + " gathers " +
-                                                     std::to_string(all[r]) + " planes, this rank " + std::to_string(mine) +
-                                                     "): call srt_comm_set_gather_planes with the same value on every rank");
-        c->planes_agreed = true;
     }
     if (c->root_local >= 0 && (size_t)c->world * n_floats > c->gathered_capacity) {
         COMM_HIP(c, hipSetDevice(device_of(c->ctx[c->root_local])));

@@ -8,13 +8,15 @@ struct srt_ctx;
 extern "C" int srt_internal_init_device_params(srt_ctx *c, uint32_t tx, uint32_t ty, uint32_t bx, uint32_t by, uint32_t chunk_w, uint32_t chunk_h,
                                                uint32_t spp, uint32_t bounce_limit, uint64_t seed, int wait);      // not exported (hidden visibility)
 
+extern "C" uint32_t srt_internal_gather_planes(const srt_ctx *c);      // planes of the context's exchange unit (3 or 9); not exported
+
 namespace srt {
 
 constexpr int kTilePlanes = 9;      // quantised rgb | unquantised sRGB | XYZ sums
 constexpr int kTileGroups = 3;      // ... in three groups of three planes; group 0 (the quantised framebuffer) is what the multi-GPU gather moves
 constexpr int kGroupPlanes = 3;
 constexpr int kTileLanes = 64;      // one wave = one 8x8 pixel tile
-constexpr int kCounters = 24;       // rays, node_visits, tri_tests, box_tests, utilisation counters (instrumented build)
+constexpr int kCounters = 32;       // rays, node_visits, tri_tests, box_tests, utilisation counters (instrumented build); [23] queue invariant, [24] hits
 
 // Kernel arguments of one render launch.  All pointers are device pointers.
 struct RenderParams {
@@ -61,12 +63,12 @@ struct RenderParams {
     uint32_t tile_group_stride;           // floats between two groups = tiles_padded * 3 * 64
     uint32_t write_parity;                // 0: only group 0 (the reference's framebuffer values) is written; 1: + the two parity groups
     unsigned long long *counters;
-    uint32_t *wave_debug;                 // instrumented build, optional: 4 words per wave (see srt_get_wave_debug)
+    uint32_t *wave_debug;                 // instrumented build, optional: OrderProfile header, then 4 words per wave (see srt_get_wave_debug)
 };
 
-// Child-order profile of an instrumented launch (srt_order_children_by_profile): the pointers travel in a header behind the per-wave
-// words of RenderParams::wave_debug (4 words per launched wave, then this struct) so that RenderParams -- the kernel argument of every
-// variant -- stays as it is.  magic == kOrderProfileMagic marks a launch that collects the profile.
+// Child-order profile of an instrumented launch (srt_order_children_by_profile): the pointers travel in a header IN FRONT of the
+// per-wave words of RenderParams::wave_debug (this struct, then 4 words per launched wave) so that RenderParams -- the kernel argument
+// of every variant -- stays as it is and the header's place does not depend on the number of waves a launch starts.  magic == kOrderProfileMagic marks a launch that collects the profile.
 struct OrderProfile {
     unsigned long long magic;
     const int32_t *leaf;       // per triangle: node index of its leaf
@@ -87,7 +89,11 @@ struct ScatterParams {
 };
 
 hipError_t launch_init_rng(uint32_t *rng, uint32_t n_lanes, uint64_t seed, hipStream_t st);
-hipError_t launch_render(const RenderParams &p, uint32_t n_cu, int mode, hipStream_t st);   // mode 0 render, 1 instrumented, 2 cost probe
+// Test knobs of a context (srt_set_test_knobs; from the environment only under SRT_TEST_KNOBS=1, read once at srt_create): they pick
+// the kernel variant / cache size a launch plan would not pick by itself, so that every instantiated variant can be held to the CPU oracle by the tests.
+struct PlanKnobs { bool wide_refs = false; int lds_cache_max = -1; };
+// mode 0 render, 1 instrumented, 2 cost probe; waves_launched (optional) = persistent waves of the launch
+hipError_t launch_render(const RenderParams &p, const PlanKnobs &knobs, uint32_t n_cu, int mode, hipStream_t st, uint32_t *waves_launched = nullptr);
 hipError_t launch_order_tiles(const uint32_t *cost, uint32_t *sorted, uint32_t *rows, uint32_t n, uint32_t n_waves,
                               uint32_t split_load_pct, uint32_t *queue_info, uint32_t order_max_pct, hipStream_t st);
 hipError_t launch_scatter(const ScatterParams &p, hipStream_t st);
@@ -99,10 +105,10 @@ hipError_t launch_op_sweep(int which, const float *a, const float *b, size_t n, 
 hipError_t launch_calib(int kind, uint32_t n_blocks, uint32_t threads, uint32_t iters, float *sink, unsigned long long *cycles, const float4 *table,
                         uint32_t n_records, hipStream_t st);
 int calib_kinds();
-bool render_narrow_refs(int n_records);
-size_t render_lds_bytes(int stack_depth, int waves_per_block, int n_cached, int n_records);
-void render_launch_shape(int stack_depth, int n_records, int n_inner, int &waves_per_block, int &n_cached);
+bool render_narrow_refs(int n_records, const PlanKnobs &k);
+size_t render_lds_bytes(int stack_depth, int waves_per_block, int n_cached, int n_records, const PlanKnobs &k);
+void render_launch_shape(int stack_depth, int n_records, int n_inner, const PlanKnobs &k, int &waves_per_block, int &n_cached);
 struct LaunchPlan { int waves_per_block, blocks_per_cu, waves_per_cu, waves_per_eu, n_cached; bool all_cached; };
-void render_launch_plan(int stack_depth, int n_records, int n_inner, LaunchPlan &lp);   // what launch_render will do for this scene
+void render_launch_plan(int stack_depth, int n_records, int n_inner, const PlanKnobs &k, LaunchPlan &lp);   // what launch_render will do for this scene
 
 }  // namespace srt

@@ -46,38 +46,37 @@ constexpr int kInnerBurst = SRT_INNER_BURST;   // at most this many inner steps 
 constexpr uint32_t kBurstDrop = SRT_BURST_DROP;   // ... and the burst ends once fewer than 1 / kBurstDrop of its lanes are still at inner records
 static inline size_t round16(size_t v) { return (v + 15) & ~(size_t)15; }
 // 16-bit child references and stack entries when the record indices fit 15 bits (a 16-bit stack slot also holds the sentinel -1).
-// SRT_WIDE_REFS=1 (test knob, read with every plan) sends small trees through the 32-bit variants as well.
-bool render_narrow_refs(int n_records) {
-    if (const char *ev = getenv("SRT_WIDE_REFS")) if (atoi(ev) != 0) return false;
-    return n_records <= 32767;
-}
-static inline bool narrow_refs(int n_records) { return render_narrow_refs(n_records); }
-static inline size_t cache_bytes(int n_cached, int n_records) { return round16((size_t)n_cached * (narrow_refs(n_records) ? 52 : 56)); }
+// PlanKnobs (test knobs of a context, srt_set_test_knobs -- never the environment of a launch): wide_refs sends small trees through the
+// 32-bit variants as well, lds_cache_max caps the LDS-resident inner records.
+bool render_narrow_refs(int n_records, const PlanKnobs &k) { return !k.wide_refs && n_records <= 32767; }
+static inline size_t cache_bytes(int n_cached, bool narrow) { return round16((size_t)n_cached * (narrow ? 52 : 56)); }
 static inline size_t stack_slots(int stack_depth) { return (size_t)(stack_depth < 1 ? 1 : stack_depth) + kStackSentinels; }
-static inline size_t stack_bytes(int stack_depth, int n_records) { return stack_slots(stack_depth) * 64 * (narrow_refs(n_records) ? 2 : 4); }
-size_t render_lds_bytes(int stack_depth, int waves_per_block, int n_cached, int n_records) {
-    return (size_t)kLdsTablesF4 * 16 + cache_bytes(n_cached, n_records) + (size_t)waves_per_block * stack_bytes(stack_depth, n_records);
+static inline size_t stack_bytes(int stack_depth, bool narrow) { return stack_slots(stack_depth) * 64 * (narrow ? 2 : 4); }
+size_t render_lds_bytes(int stack_depth, int waves_per_block, int n_cached, int n_records, const PlanKnobs &k) {
+    const bool narrow = render_narrow_refs(n_records, k);
+    return (size_t)kLdsTablesF4 * 16 + cache_bytes(n_cached, narrow) + (size_t)waves_per_block * stack_bytes(stack_depth, narrow);
 }
 // One workgroup per CU when the stacks leave room for a useful cache: 16 waves share it.  Deep trees (big stacks)
 // fall back to smaller groups.  Only INNER records are cached (n_inner of them, breadth-first order).
-void render_launch_shape(int stack_depth, int n_records, int n_inner, int &waves_per_block, int &n_cached) {
-    const size_t stack = stack_bytes(stack_depth, n_records);
+void render_launch_shape(int stack_depth, int n_records, int n_inner, const PlanKnobs &k, int &waves_per_block, int &n_cached) {
+    const bool narrow = render_narrow_refs(n_records, k);
+    const size_t stack = stack_bytes(stack_depth, narrow);
     waves_per_block = 16;
     while (waves_per_block > 1 && (size_t)kLdsTablesF4 * 16 + waves_per_block * stack + 16 * 1024 > kLdsBudget) waves_per_block /= 2;
     const size_t blocks_per_cu = 16 / waves_per_block;
     const size_t per_block = kLdsBudget / blocks_per_cu;
     const size_t fixed = (size_t)kLdsTablesF4 * 16 + waves_per_block * stack + 64;
-    size_t room = per_block > fixed ? (per_block - fixed) / (narrow_refs(n_records) ? 52 : 56) : 0;
+    size_t room = per_block > fixed ? (per_block - fixed) / (narrow ? 52 : 56) : 0;
     if (room > (size_t)n_inner) room = (size_t)n_inner;
-    if (const char *ev = getenv("SRT_LDS_CACHE_MAX")) room = std::min(room, (size_t)std::max(0, atoi(ev)));   // experiment knob
+    if (k.lds_cache_max >= 0) room = std::min(room, (size_t)k.lds_cache_max);
     n_cached = (int)room;
 }
 // The launch plan of a scene: one 16-wave workgroup per CU (4 waves / SIMD at this kernel's 126 VGPRs) whenever the stacks leave
 // room for a useful cache; ALL_CACHED when the whole inner tree fits it.  (Round 3 measured a second shape for trees that do not
 // fit -- 256-thread workgroups, five per CU, 96 VGPRs, five waves per SIMD -- at -5 % on the 100k-triangle mesh and dropped it:
 // profiles/r03/experiments/cfg5_negative_results.txt.)
-void render_launch_plan(int stack_depth, int n_records, int n_inner, LaunchPlan &lp) {
-    render_launch_shape(stack_depth, n_records, n_inner, lp.waves_per_block, lp.n_cached);
+void render_launch_plan(int stack_depth, int n_records, int n_inner, const PlanKnobs &k, LaunchPlan &lp) {
+    render_launch_shape(stack_depth, n_records, n_inner, k, lp.waves_per_block, lp.n_cached);
     lp.all_cached = lp.n_cached == n_inner;
     lp.waves_per_eu = 4;
     lp.blocks_per_cu = 16 / lp.waves_per_block;
@@ -218,7 +217,7 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
     bool parked = false, exclusive = false;
     OrderProfile prof;      // instrumented build only: see srt_internal.h
     prof.magic = 0;
-    if (COUNT && P.wave_debug) prof = *reinterpret_cast<const OrderProfile *>(P.wave_debug + 4u * (size_t)gridDim.x * (blockDim.x >> 6));
+    if (COUNT && P.wave_debug) prof = *reinterpret_cast<const OrderProfile *>(P.wave_debug);      // (fixed place: in front of the per-wave words)
     unsigned long long t_shade = 0, t_inner = 0, t_fringe = 0, t_mark = 0;   // instrumented build: wave cycles per phase
     if (COUNT) t_mark = __builtin_amdgcn_s_memtime();
     const unsigned long long t_born = t_mark;
@@ -226,6 +225,7 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
     uint32_t cur_tile_local = 0, pixel_iters0 = 0;   // probe / instrumented builds
     uint32_t pixel_rays0 = 0, max_pix_iters = 0, max_pix_rays = 0;
     uint32_t w_shade_passes = 0, l_shade = 0, l_cam = 0, w_reject_iters = 0;   // instrumented build: shading-phase occupancy
+    uint32_t n_hits = 0;                     // instrumented build: queries that found a triangle (one shading record each)
 
     for (;;) {
         // parked lanes wake up when no lane of the wave holds a pixel any more
@@ -322,6 +322,7 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
                     rd = scatter_direction;                                                 // :97
                     hit_scattered = did_scatter;
                     was_hit = true;
+                    if (COUNT) n_hits++;
                 }
                 // r_in.mul_spectrum(spectral_distribution) (:95), after valid_wavelengths was updated (Q8).  A path that ends
                 // here (miss, or no scattered ray) is converted in the same pass: dev_spectrum_to_XYZ (color.cu:88-104) needs
@@ -430,7 +431,14 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
                     // sorted order (the most expensive tiles of a launch used to share a handful of CUs for their whole life), and
                     // the placement no longer depends on the order in which the waves' first atomics arrive.  Later rows come
                     // from the shared counter, which starts behind the assigned ones.
-                    const bool assigned = SRT_ASSIGN_FIRST_ROW != 0 && m == ~0ull && ((U->first_row_taken >> wave) & 1u) == 0u;
+                    // Invariant: a wave's FIRST fetch is made by all 64 lanes (every lane starts without a pixel, alive and not parked,
+                    // and lane_limit is applied after the fetch), so `m == ~0` holds whenever the wave's bit is still clear and the
+                    // assigned row is handed out whole.  The instrumented build checks it (counter 23, srt_get_stats fails on it): a
+                    // partial first fetch would leave the assigned row unrendered.  (Each wave reads and sets only its own bit; the
+                    // atomicOr of the other waves touch other bits of the word.)
+                    const bool row_open = SRT_ASSIGN_FIRST_ROW != 0 && ((U->first_row_taken >> wave) & 1u) == 0u;
+                    if (COUNT && row_open && m != ~0ull && lane == (uint32_t)leader) atomicAdd(&P.counters[23], 1ull);
+                    const bool assigned = row_open && m == ~0ull;
                     if (assigned) {      // (the per-wave "taken" bit lives in LDS: nothing stays live in the persistent loop for it)
                         if (lane == 0) atomicOr((unsigned int *)&U->first_row_taken, 1u << wave);
                         base = (assigned_band(wave) * gridDim.x + blockIdx.x) * 64u;
@@ -655,8 +663,9 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
                 atomicAdd(&P.counters[4], (unsigned long long)ts.w_iters);   // wave-uniform
                 atomicAdd(&P.counters[5], (unsigned long long)ts.w_alive);
             }
-            const uint32_t nn = wave_sum(ts.n_nan);
+            const uint32_t nn = wave_sum(ts.n_nan), nh = wave_sum(n_hits);
             if (lane == 0) {
+                atomicAdd(&P.counters[24], (unsigned long long)nh);
                 atomicAdd(&P.counters[6], (unsigned long long)nn);
                 atomicAdd(&P.counters[7], (unsigned long long)ts.w_fringe);
                 atomicAdd(&P.counters[8], (unsigned long long)ts.l_fringe);
@@ -682,7 +691,7 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
                 atomicAdd(&P.counters[18], (unsigned long long)w_reject_iters);
                 if (P.wave_debug) {
                     // per wave: end of life and of the queue (units of 256 cycles since birth), rays, the most expensive pixel (rays)
-                    uint32_t *w = P.wave_debug + 4u * (blockIdx.x * (blockDim.x >> 6) + wave);
+                    uint32_t *w = P.wave_debug + sizeof(OrderProfile) / 4u + 4u * (blockIdx.x * (blockDim.x >> 6) + wave);
                     w[0] = (uint32_t)((t_end - t_born) >> 8); w[1] = dry_first; w[2] = r; w[3] = wave_max_pix_rays;
                 }
                 atomicAdd(&P.counters[19], 1ull);
@@ -944,7 +953,7 @@ hipError_t launch_init_rng(uint32_t *rng, uint32_t n_lanes, uint64_t seed, hipSt
 }
 
 template <int MODE, bool NARROW, bool ALL_CACHED>
-static hipError_t launch_render_cached(const RenderParams &p_in, const LaunchPlan &lp, uint32_t n_cu, hipStream_t st) {
+static hipError_t launch_render_cached(const RenderParams &p_in, const LaunchPlan &lp, const PlanKnobs &knobs, uint32_t n_cu, hipStream_t st, uint32_t *waves_launched) {
     RenderParams p = p_in;
     int wpb = lp.waves_per_block;
     uint32_t waves_per_cu = (uint32_t)lp.waves_per_cu;
@@ -954,7 +963,7 @@ static hipError_t launch_render_cached(const RenderParams &p_in, const LaunchPla
         waves_per_cu = p.waves_per_cu_override;
     }
     p.n_cached = lp.n_cached;
-    const size_t lds = render_lds_bytes(p.stack_depth, wpb, lp.n_cached, p.n_records);
+    const size_t lds = render_lds_bytes(p.stack_depth, wpb, lp.n_cached, p.n_records, knobs);
     // per launch, not once per process: the attribute belongs to the function ON THE CURRENT DEVICE, and one process may
     // drive several GPUs (srt_comm_init_all); the call is a host-side table update
     {
@@ -965,26 +974,28 @@ static hipError_t launch_render_cached(const RenderParams &p_in, const LaunchPla
     uint32_t n_waves = n_cu * waves_per_cu;
     if (n_waves > p.queue_rows_bound) n_waves = p.queue_rows_bound;     // (upper bound known to the host)
     const uint32_t n_blocks = (n_waves + (uint32_t)wpb - 1) / (uint32_t)wpb;
+    if (waves_launched) *waves_launched = n_blocks * (uint32_t)wpb;
     hipLaunchKernelGGL((render_kernel<MODE, NARROW, ALL_CACHED>), dim3(n_blocks), dim3(64 * wpb), lds, st, p);
     return hipGetLastError();
 }
 
 template <int MODE, bool NARROW>
-static hipError_t launch_render_mode(const RenderParams &p, uint32_t n_cu, hipStream_t st) {
+static hipError_t launch_render_mode(const RenderParams &p, const PlanKnobs &knobs, uint32_t n_cu, hipStream_t st, uint32_t *waves_launched) {
     LaunchPlan lp;
-    render_launch_plan(p.stack_depth, p.n_records, p.n_inner, lp);
+    render_launch_plan(p.stack_depth, p.n_records, p.n_inner, knobs, lp);
     // (the ALL_CACHED variant reads packed 96-byte FRINGE records by a literal stride: never pick it for a scene that was uploaded
-    // with padded records -- the plan can only differ from the upload's when SRT_LDS_CACHE_MAX changed in between)
+    // with padded records -- the plan can only differ from the upload's when the context's test knobs changed in between)
     if (lp.all_cached && p.fringe_stride != 96u) lp.all_cached = false;
-    return lp.all_cached ? launch_render_cached<MODE, NARROW, true>(p, lp, n_cu, st) : launch_render_cached<MODE, NARROW, false>(p, lp, n_cu, st);
+    return lp.all_cached ? launch_render_cached<MODE, NARROW, true>(p, lp, knobs, n_cu, st, waves_launched) : launch_render_cached<MODE, NARROW, false>(p, lp, knobs, n_cu, st, waves_launched);
 }
 
-hipError_t launch_render(const RenderParams &p, uint32_t n_cu, int mode, hipStream_t st) {
+hipError_t launch_render(const RenderParams &p, const PlanKnobs &knobs, uint32_t n_cu, int mode, hipStream_t st, uint32_t *waves_launched) {
+    if (waves_launched) *waves_launched = 0;
     if (p.tiles_local == 0) return hipSuccess;
-    const bool narrow = narrow_refs(p.n_records);
-    if (mode == 1) return narrow ? launch_render_mode<1, true>(p, n_cu, st) : launch_render_mode<1, false>(p, n_cu, st);
-    if (mode == 2) return narrow ? launch_render_mode<2, true>(p, n_cu, st) : launch_render_mode<2, false>(p, n_cu, st);
-    return narrow ? launch_render_mode<0, true>(p, n_cu, st) : launch_render_mode<0, false>(p, n_cu, st);
+    const bool narrow = render_narrow_refs(p.n_records, knobs);
+    if (mode == 1) return narrow ? launch_render_mode<1, true>(p, knobs, n_cu, st, waves_launched) : launch_render_mode<1, false>(p, knobs, n_cu, st, waves_launched);
+    if (mode == 2) return narrow ? launch_render_mode<2, true>(p, knobs, n_cu, st, waves_launched) : launch_render_mode<2, false>(p, knobs, n_cu, st, waves_launched);
+    return narrow ? launch_render_mode<0, true>(p, knobs, n_cu, st, waves_launched) : launch_render_mode<0, false>(p, knobs, n_cu, st, waves_launched);
 }
 
 hipError_t launch_order_tiles(const uint32_t *cost, uint32_t *sorted, uint32_t *rows, uint32_t n, uint32_t n_waves,

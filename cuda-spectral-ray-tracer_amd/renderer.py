@@ -50,7 +50,16 @@ class Renderer:
         """dict(waves_per_cu, n_cached, all_cached, narrow_refs) of the uploaded scene's render launch"""
         w, n, a, r = C.c_int(), C.c_int(), C.c_int(), C.c_int()
         self._ck(B.lib().srt_launch_plan(self._h, C.byref(w), C.byref(n), C.byref(a), C.byref(r)))
-        return dict(waves_per_cu=w.value, n_cached=n.value, all_cached=bool(a.value), narrow_refs=bool(r.value))
+        return dict(waves_per_cu=w.value, n_cached=n.value, all_cached=bool(a.value), narrow_refs=bool(r.value), test_knobs=self.test_knobs())
+
+    def set_test_knobs(self, wide_refs=False, lds_cache_max=-1, lane_limit=0):
+        """tests / tools only (srt_c_api.h): force kernel variants the plan would not pick; upload the scene again afterwards"""
+        self._ck(B.lib().srt_set_test_knobs(self._h, 1 if wide_refs else 0, int(lds_cache_max), int(lane_limit)))
+
+    def test_knobs(self):
+        w, m, l, e = C.c_int(), C.c_int(), C.c_uint32(), C.c_int()
+        self._ck(B.lib().srt_get_test_knobs(self._h, C.byref(w), C.byref(m), C.byref(l), C.byref(e)))
+        return dict(wide_refs=bool(w.value), lds_cache_max=m.value, lane_limit=l.value, from_env=bool(e.value))
 
     def set_camera(self, cam):
         self._ck(B.lib().srt_set_camera(self._h, C.byref(cam)))
@@ -134,6 +143,7 @@ class Renderer:
         d["util"] = list(st.util)
         d["shade"] = list(st.shade)
         d["waves"] = list(st.waves)
+        d["hits"] = st.hits
         d["max_pixel_node_visits"], d["max_pixel_rays"] = st.reserved[0], st.reserved[1]
         return d
 

@@ -93,6 +93,9 @@ typedef struct {
      * their state machine to their exit), [2] the longest life, [3] sum of the cycles waves lived on after the pixel queue had
      * run dry for them (drain time: lanes finishing their last pixels).  mean / max life = [1] / ([0] * [2]). */
     uint64_t waves[4];
+    /* instrumented kernel only: closest-hit queries that found a triangle (each reads one 48-byte shading record); rays - hits =
+     * misses (background look-up) + queries answered without traversal */
+    uint64_t hits;
 } srt_stats;
 
 typedef struct srt_scene srt_scene;   /* host-side flattened scene (replaces scene_manager's device heap) */
@@ -197,6 +200,16 @@ SRT_API int srt_set_camera(srt_ctx *ctx, const srt_camera_data *cam);
  * records resident in LDS, whether that is the whole inner tree (kernel variant ALL_CACHED) and whether record references fit 15
  * bits (variant NARROW).  Any pointer may be NULL. */
 SRT_API int srt_launch_plan(const srt_ctx *ctx, int *waves_per_cu, int *n_cached, int *all_cached, int *narrow_refs);
+/* TEST KNOBS of a context (no reference counterpart; tests/ and tools/ only).  They force a launch through kernel variants the plan
+ * would not pick for the scene, so that every instantiated variant is held to the oracle: wide_refs != 0 -> 32-bit child references
+ * for small trees too; lds_cache_max >= 0 caps the inner records kept in LDS (0: every inner record from L2; -1: no cap);
+ * lane_limit > 0 renders only the first lane_limit pixels of every 8x8 tile (latency experiments; 0: all 64).  Defaults 0 / -1 / 0.
+ * Upload the scene again after a change.  The environment never changes them at launch time: SRT_WIDE_REFS, SRT_LDS_CACHE_MAX and
+ * SRT_DEBUG_LANE_LIMIT are read ONCE, at srt_create, and ONLY when SRT_TEST_KNOBS=1 is set as well -- a stray variable in a user's
+ * shell does not alter the kernel that runs.  srt_get_test_knobs reports what the context uses (from_env: 1 if srt_create took a
+ * value from the environment); srt_launch_plan reflects it.  Any out pointer may be NULL. */
+SRT_API int srt_set_test_knobs(srt_ctx *ctx, int wide_refs, int lds_cache_max, uint32_t lane_limit);
+SRT_API int srt_get_test_knobs(const srt_ctx *ctx, int *wide_refs, int *lds_cache_max, uint32_t *lane_limit, int *from_env);
 /* Dynamic LDS bytes of one workgroup of that launch (tables + inner-record cache + traversal stacks): the counterpart of the
  * reference's shared_mem_size (rendering/rendering.cu:290-301), which its run log reports as "shared memory byte size" (:342). */
 SRT_API int srt_launch_lds_bytes(const srt_ctx *ctx, size_t *bytes);
@@ -240,8 +253,9 @@ SRT_API int srt_read_fb(srt_ctx *ctx, float *r, float *g, float *b);
 /* D2H + the un-swizzle of render_manager::update_fb (render_manager.cuh:68-142) done on the device:
  * writes the last rendered chunk into row-major image planes of width image_width at (offx, offy). */
 SRT_API int srt_read_fb_rowmajor(srt_ctx *ctx, float *r, float *g, float *b, uint32_t image_width, uint32_t image_height);
-/* Parity planes, block-linear: which = 1 unquantised sRGB in [0,1] (value before expand_sRGB), 2 = XYZ sums.  SRT_ERR_UNSUPPORTED
- * when the last scatter did not write them (multi-GPU frame with the default 3-plane exchange unit). */
+/* Parity planes, block-linear: which = 1 unquantised sRGB in [0,1] (value before expand_sRGB), 2 = XYZ sums.  ANY context -- single
+ * GPU included -- writes them only when srt_set_gather_planes(ctx, 9) was called before srt_render_chunk: with the default 3 planes
+ * the kernel and the scatter move the quantised framebuffer alone and this call returns SRT_ERR_UNSUPPORTED. */
 SRT_API int srt_read_fb_aux(srt_ctx *ctx, int which, float *p0, float *p1, float *p2);
 
 /* Scheduling introspection: per-local-tile traversal cost measured by the probe of the last ordered launch (n = tiles_local; n = 2 *
@@ -272,9 +286,9 @@ SRT_API int srt_trace_rays(srt_ctx *ctx, const float *rays, size_t n, float *out
  * sweep"); used to prove the device's + - * / sqrt fmin cast and srt_powf bits equal the host's. */
 SRT_API int srt_device_op_sweep(srt_ctx *ctx, int which, const float *a, const float *b, size_t n, float *out);
 
-SRT_API int srt_ctx_device(const srt_ctx *ctx);
+SRT_API int srt_ctx_device(const srt_ctx *ctx);                 /* HIP device index of the context */
 /* compute units of the context's GPU (a render launch keeps srt_launch_plan's waves_per_cu x 64 pixels in flight on each) */
-SRT_API int srt_ctx_cu_count(const srt_ctx *ctx);               /* HIP device index of the context */
+SRT_API int srt_ctx_cu_count(const srt_ctx *ctx);
 
 /* ---------------------------------------------------------------------------------------------------
  * Multi-GPU.  The reference's caller renders chunk after chunk on ONE GPU
@@ -297,9 +311,10 @@ SRT_API int srt_comm_init_rank(srt_ctx *ctx, const unsigned char id[SRT_COMM_ID_
  * An RCCL the host process already mapped (PyTorch's) is re-used; SRT_RCCL_LIB names an explicit library. */
 SRT_API int srt_comm_available(void);
 /* Planes the gather moves: 3 (default) = the quantised framebuffer, 12 B / pixel; 9 = + the parity planes (72 B / pixel).
- * With one process per GPU EVERY rank must set the same value: the first srt_render_frame_multi after a change exchanges the
- * counts (one 4-byte all-gather) and fails with SRT_ERR_INVALID on every rank when they differ, instead of entering ncclGather
- * with mismatched counts.  After a 3-plane frame rank 0's parity planes are not this frame's: srt_read_fb_aux returns
+ * With one process per GPU EVERY rank must set the same value: every srt_render_frame_multi of such a communicator starts with a
+ * 4-byte all-gather of the count each rank's context will really use (whichever call set it, srt_set_gather_planes on the wrapped
+ * context included) and fails with SRT_ERR_INVALID on EVERY rank when they differ -- all ranks make the same collective calls, so a
+ * disagreement is an error, never a hang in ncclGather.  After a 3-plane frame rank 0's parity planes are not this frame's: srt_read_fb_aux returns
  * SRT_ERR_UNSUPPORTED until a 9-plane frame (or a single-GPU scatter) has written them. */
 SRT_API int srt_comm_set_gather_planes(srt_comm *comm, uint32_t planes);
 SRT_API void srt_comm_destroy(srt_comm *comm);                 /* destroys the contexts srt_comm_init_all created */

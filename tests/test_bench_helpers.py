@@ -38,3 +38,37 @@ def test_bench_refuses_to_run_without_a_gpu():
         out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, env=env, capture_output=True, text=True, timeout=300)
         assert out.returncode != 0 and "needs a GPU" in (out.stderr + out.stdout)
         assert not [l for l in out.stdout.splitlines() if l.startswith("{")]        # and prints no line
+
+
+def test_hsa_ipc_mode_is_set_before_torch_is_imported():
+    """HSA_ENABLE_IPC_MODE_LEGACY is read when the HSA runtime starts, so bench.py must put it into the environment at
+    module level, before the first `import torch` of the file (which lives inside main())."""
+    import ast
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    tree = ast.parse(src)
+    set_line, first_torch = None, None
+    for node in tree.body:      # module level only
+        if isinstance(node, ast.Expr) and "HSA_ENABLE_IPC_MODE_LEGACY" in ast.get_source_segment(src, node):
+            set_line = node.lineno
+    for node in ast.walk(tree):
+        names = []
+        if isinstance(node, ast.Import):
+            names = [a.name for a in node.names]
+        elif isinstance(node, ast.ImportFrom):
+            names = [node.module or ""]
+        if any(n == "torch" or n.startswith("torch.") for n in names):
+            first_torch = node.lineno if first_torch is None else min(first_torch, node.lineno)
+    assert set_line is not None and first_torch is not None and set_line < first_torch
+    # and importing the module (no GPU needed) leaves the variable set
+    env = {k: v for k, v in os.environ.items() if k != "HSA_ENABLE_IPC_MODE_LEGACY"}
+    code = "import importlib.util, os; s = importlib.util.spec_from_file_location('b', %r); m = importlib.util.module_from_spec(s); s.loader.exec_module(m); print(os.environ['HSA_ENABLE_IPC_MODE_LEGACY'])" % os.path.join(ROOT, "bench.py")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert out.stdout.strip() == "0", out.stderr[-1000:]
+
+
+def test_traffic_is_attached_to_every_record_with_a_two_point_entry():
+    b = _bench()
+    entry = {"fabric_bytes_per_pixel": 100.0, "fabric_bytes_per_ray": 2.0, "fabric_note": "test"}
+    t = b.traffic_of(entry, "profiles/x.json", pixels=1000, rays=50000.0, kms=2.0)
+    assert t["traffic"] == 100.0 * 1000 + 2.0 * 50000 and abs(t["traffic_GBs"] - t["traffic"] / 2e-3 / 1e9) < 1e-9
+    assert b.traffic_of({"lane_ops_per_ray": 1.0}, "x", 1, 1.0, 1.0) == {"traffic": None}

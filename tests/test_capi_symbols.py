@@ -93,3 +93,22 @@ def test_kernel_identity_from_the_code_object(srt):
         for scene, variant in (("scene_100", (1, 1)), ("scene_101", (0, 0)), ("scene_1", (1, 1))):
             assert len(doc[scene]["kernel_code_sha256"]) == 64
             print("%s: PMC pass %s this build's render_kernel<0,%d,%d>" % (scene, "==" if doc[scene]["kernel_code_sha256"] == hs[variant] else "!=", *variant))
+
+
+def test_test_knobs_are_fenced():
+    """no launch-time getenv decides the kernel variant.  srt_kernels.hip (the launch plan and the launchers) reads no
+    environment at all; srt_capi.cpp reads SRT_WIDE_REFS / SRT_LDS_CACHE_MAX / SRT_DEBUG_LANE_LIMIT only inside the SRT_TEST_KNOBS=1
+    block of srt_create; srt_comm.cpp honours SRT_COMM_TEST_SAME_DEVICE only next to SRT_TEST_KNOBS.  (The GPU suite checks the
+    behaviour: tests/test_gpu_parity.py::test_stray_knob_variables_do_not_change_the_plan.)"""
+    csrc = os.path.join(ROOT, "cuda-spectral-ray-tracer_amd", "csrc")
+    kern = open(os.path.join(csrc, "srt_kernels.hip")).read()
+    assert "getenv" not in kern
+    capi = open(os.path.join(csrc, "srt_capi.cpp")).read()
+    a = capi.index('getenv("SRT_TEST_KNOBS")')
+    b = capi.index("}", capi.index('getenv("SRT_LDS_CACHE_MAX")'))
+    for name in ("SRT_WIDE_REFS", "SRT_LDS_CACHE_MAX", "SRT_DEBUG_LANE_LIMIT"):
+        hits = [m.start() for m in re.finditer(r'getenv\("%s"\)' % name, capi)]
+        assert len(hits) == 1 and a < hits[0] < b, name
+    comm = open(os.path.join(csrc, "srt_comm.cpp")).read()
+    i = comm.index('getenv("SRT_COMM_TEST_SAME_DEVICE")')
+    assert 'getenv("SRT_TEST_KNOBS")' in comm[i:i + 200]

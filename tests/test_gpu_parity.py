@@ -647,9 +647,114 @@ for world in (2, 3):
     comm.close()
 print('mock transport ok')
 """ % (root, os.path.join(root, "tests"))
-    env = dict(os.environ, SRT_RCCL_LIB=mock, SRT_COMM_TEST_SAME_DEVICE="1")
+    env = dict(os.environ, SRT_RCCL_LIB=mock, SRT_COMM_TEST_SAME_DEVICE="1", SRT_TEST_KNOBS="1")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "mock transport ok" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])
+
+
+def test_comm_process_per_gpu_ranks_agree_or_fail_together_mock_transport():
+    """the plane-count agreement of a process-per-GPU communicator (srt_comm_init_rank).  Two ranks of world 2,
+    each driven by its own THREAD of one process on device 0 over the test transport (which now has a rendezvous all-gather / gather
+    for such communicators): (1) both ranks at the default 3 planes and both at 9 -> the frame equals the single-context image;
+    (2) rank 1 switches ITS CONTEXT to 9 planes behind the communicator's back (srt_set_gather_planes on the wrapped context --
+    exactly what render_image() does) after a good frame, rank 0 does not -> BOTH ranks get SRT_ERR_INVALID with the same message
+    from the same collective, nobody enters ncclGather alone, nothing hangs; (3) they agree again -> the next frame is good."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    mock = os.path.join(root, "tests", "cpp", "_build", "libmock_rccl.so")
+    if not os.path.exists(mock):
+        pytest.skip("tests/cpp/_build/libmock_rccl.so not built (__graft_entry__.build())")
+    code = """
+import importlib, sys, threading
+import numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+srt = importlib.import_module('cuda-spectral-ray-tracer_amd')
+from helpers import assert_planes_equal
+scene = srt.Scene.builtin(srt.SCENE_PRISM).build_bvh(srt.BVH_REFERENCE, 1984)
+W, H, spp, depth = 96, 64, 6, 8
+cam = scene.default_camera(W, H)
+ref = srt.render_image(scene, cam, W, H, spp, depth)
+ident = srt.Comm.unique_id()
+world = 2
+rs = [srt.Renderer(0) for _ in range(world)]
+comms = [None] * world
+def make(rank):
+    comms[rank] = srt.Comm.init_rank(rs[rank], ident, rank, world)
+ts = [threading.Thread(target=make, args=(k,)) for k in range(world)]
+[t.start() for t in ts]; [t.join(60) for t in ts]
+assert all(c is not None and c.world == 2 for c in comms)
+def frame(rank, result):
+    try:
+        c = comms[rank]
+        c.upload_scene(scene); c.set_camera(cam)
+        c.init_device_params(W, H, spp, depth, 1984)
+        c.render_frame(W, H); c.synchronize()
+        result[rank] = 'ok'
+    except srt.SrtError as e:
+        result[rank] = e
+def run():
+    result = [None] * world
+    ts = [threading.Thread(target=frame, args=(k, result)) for k in range(world)]
+    [t.start() for t in ts]
+    [t.join(120) for t in ts]
+    assert not any(t.is_alive() for t in ts), 'a rank hangs in the exchange'
+    return result
+# (1) agreement at 3 and at 9 planes
+assert run() == ['ok', 'ok']
+assert_planes_equal(rs[0].read_fb(), ref['fb'], '2 ranks, 3 planes')
+for c in comms: c.set_gather_planes(9)
+assert run() == ['ok', 'ok']
+assert_planes_equal(rs[0].read_fb(), ref['fb'], '2 ranks, 9 planes'); assert_planes_equal(rs[0].read_fb_aux(2), ref['xyz'], '2 ranks xyz')
+# (2) one rank changes the count on the wrapped context, not through the communicator
+rs[1].set_gather_planes(3)
+res = run()
+assert all(isinstance(r, srt.SrtError) and r.code == -1 and 'disagree on the exchange unit' in str(r) for r in res), res
+assert 'rank 0 gathers 9 planes, rank 1 3' in str(res[0]) and 'rank 0 gathers 9 planes, rank 1 3' in str(res[1]), res
+# (3) agreement restored (through the context on the other rank, too)
+rs[0].set_gather_planes(3)
+assert run() == ['ok', 'ok']
+assert_planes_equal(rs[0].read_fb(), ref['fb'], '2 ranks, 3 planes again')
+for c in comms: c.close()
+for r in rs: r.close()
+print('agreement ok')
+""" % (root, os.path.join(root, "tests"))
+    env = dict(os.environ, SRT_RCCL_LIB=mock, SRT_TEST_KNOBS="1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "agreement ok" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])
+
+
+def test_stray_knob_variables_do_not_change_the_plan():
+    """SRT_WIDE_REFS / SRT_LDS_CACHE_MAX / SRT_DEBUG_LANE_LIMIT in a user's environment do nothing by themselves (the
+    launch plan of a small scene stays NARROW + ALL_CACHED and the image is complete); with SRT_TEST_KNOBS=1 they are read once at
+    srt_create, and srt_get_test_knobs / launch_plan() report them."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = """
+import importlib, json, sys
+sys.path.insert(0, %r)
+srt = importlib.import_module('cuda-spectral-ray-tracer_amd')
+scene = srt.Scene.builtin(srt.SCENE_PRISM).build_bvh(srt.BVH_REFERENCE, 1984)
+r = srt.Renderer(0)
+out = srt.render_image(scene, scene.default_camera(40, 24), 40, 24, 2, 4, renderer=r)
+plan = r.launch_plan()
+print(json.dumps(dict(plan=plan, rays=out['stats']['rays'])))
+""" % root
+    base = {k: v for k, v in os.environ.items() if not k.startswith("SRT_")}
+
+    def run(env):
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return [__import__("json").loads(l) for l in out.stdout.splitlines() if l.startswith("{")][0]
+    plain = run(base)
+    stray = run(dict(base, SRT_WIDE_REFS="1", SRT_LDS_CACHE_MAX="0", SRT_DEBUG_LANE_LIMIT="3"))
+    assert stray == plain and plain["plan"]["narrow_refs"] and plain["plan"]["all_cached"]
+    assert plain["plan"]["test_knobs"] == dict(wide_refs=False, lds_cache_max=-1, lane_limit=0, from_env=False)
+    fenced = run(dict(base, SRT_TEST_KNOBS="1", SRT_WIDE_REFS="1", SRT_LDS_CACHE_MAX="0", SRT_DEBUG_LANE_LIMIT="3"))
+    assert fenced["plan"]["test_knobs"] == dict(wide_refs=True, lds_cache_max=0, lane_limit=3, from_env=True)
+    assert not fenced["plan"]["narrow_refs"] and not fenced["plan"]["all_cached"] and fenced["plan"]["n_cached"] == 0
+    assert fenced["rays"] < plain["rays"]      # only 3 pixels of every tile were rendered
 
 
 def test_bench_single_process_two_ranks_mock_transport():
@@ -675,7 +780,7 @@ def test_bench_single_process_two_ranks_mock_transport():
         return json.loads(lines[0])
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     one = run(1, env)
-    two = run(2, dict(env, SRT_RCCL_LIB=mock, SRT_COMM_TEST_SAME_DEVICE="1"))
+    two = run(2, dict(env, SRT_RCCL_LIB=mock, SRT_COMM_TEST_SAME_DEVICE="1", SRT_TEST_KNOBS="1"))
     assert one["n_gpus"] == 1 and two["n_gpus"] == 2
     assert "one process drives all GPUs" in two["config"]["launch_mode"] and "srt_comm_init_all" in two["config"]["launch_mode"]
     assert "ncclGather inside libsrt_hip.so" in two["config"]["gather"], two["config"]["gather"]
@@ -691,21 +796,7 @@ def test_bench_single_process_two_ranks_mock_transport():
     assert "nan_direction_rays" in two["config"]
 
 
-def _custom_scene(srt, tris, mats, bg_rgb=(0.5, 0.5, 0.5)):
-    """Scene from raw arrays (the boundary's srt_scene_set_* path): tris = [(v0, v1, v2, mat, aa_plane)], mats = [(type, rgb, fuzz, power)]."""
-    import ctypes as C
-    B = srt.binding
-    T = (B.TriIn * len(tris))()
-    for k, (v0, v1, v2, mat, aap) in enumerate(tris):
-        T[k].v0[:] = v0; T[k].v1[:] = v1; T[k].v2[:] = v2; T[k].mat_index = mat; T[k].aa_plane = aap
-    M = (B.Material * len(mats))()
-    for k, (mtype, rgb, fuzz, power) in enumerate(mats):
-        M[k].col[:] = rgb; M[k].reflection_fuzz = fuzz; M[k].material_type = mtype; M[k].emission_power = power
-        M[k].sellmeier_B[:] = (1.03961212, 0.231792344, 1.01046945); M[k].sellmeier_C[:] = (1.03961212, 0.231792344, 1.01046945)   # Q1: C := B
-        B.check(B.lib().srt_material_bake(C.byref(M[k])))
-    bg = np.zeros(B.N_CIE, np.float32)
-    B.check(B.lib().srt_background_spectrum((C.c_float * 3)(*bg_rgb), B.fptr(bg)))
-    return srt.Scene.from_arrays(T, M, bg)
+from helpers import custom_scene as _custom_scene, fuzz_case      # noqa: E402  (shared with tests/test_oracle_digests.py)
 
 
 @pytest.mark.parametrize("count_traversal", VARIANTS)
@@ -833,17 +924,19 @@ def test_partly_cached_narrow_tree_forced_on_small_scenes(srt, gpu, orc, monkeyp
     """render_kernel<MODE, NARROW = true, ALL_CACHED = false>: 16-bit child references, inner records beyond an LDS prefix served by
     L2 -- the variant mid-size scenes (about 5 k to 60 k triangles) launch, which neither the small test scenes (whole tree in LDS)
     nor cfg 5's mesh (32-bit references) reach.  Forced here on the small scenes by capping the LDS cache at `cap` records
-    (SRT_LDS_CACHE_MAX, read with every launch plan; 0 = every inner record comes from L2), both kernel builds."""
-    monkeypatch.setenv("SRT_LDS_CACHE_MAX", str(cap))
+    (srt_set_test_knobs; 0 = every inner record comes from L2), both kernel builds."""
+    gpu.set_test_knobs(lds_cache_max=cap)
     scene = srt.Scene.builtin(sid, 0).build_bvh(mode, 1984)
-    cam = scene.default_camera(W, H)
-    out = srt.render_image(scene, cam, W, H, spp, depth, renderer=gpu, count_traversal=count_traversal)
-    plan = gpu.launch_plan()
-    assert plan["narrow_refs"] and not plan["all_cached"] and plan["n_cached"] <= cap
-    ref = oracle_scene_for(orc, scene, mode).render(cam, W, H, spp, depth)
-    _assert_render_matches(out, ref, "scene %d cap %d" % (sid, cap), count_traversal, scene.n_tris)
-    monkeypatch.delenv("SRT_LDS_CACHE_MAX")
-    gpu.upload_scene(scene)      # (leave the session's context with a plan that matches its upload)
+    try:
+        cam = scene.default_camera(W, H)
+        out = srt.render_image(scene, cam, W, H, spp, depth, renderer=gpu, count_traversal=count_traversal)
+        plan = gpu.launch_plan()
+        assert plan["narrow_refs"] and not plan["all_cached"] and plan["n_cached"] <= cap and plan["test_knobs"]["lds_cache_max"] == cap
+        ref = oracle_scene_for(orc, scene, mode).render(cam, W, H, spp, depth)
+        _assert_render_matches(out, ref, "scene %d cap %d" % (sid, cap), count_traversal, scene.n_tris)
+    finally:
+        gpu.set_test_knobs()
+        gpu.upload_scene(scene)      # (leave the session's context with a plan that matches its upload)
 
 
 @pytest.mark.parametrize("count_traversal", VARIANTS)
@@ -851,17 +944,21 @@ def test_partly_cached_narrow_tree_forced_on_small_scenes(srt, gpu, orc, monkeyp
 def test_wide_references_forced_on_small_scenes(srt, gpu, orc, monkeypatch, sid, mode, W, H, spp, depth, count_traversal):
     """render_kernel<MODE, NARROW = false, ALL_CACHED = true>: 32-bit references with the whole inner tree in LDS.  No real tree
     gets there (more than 32 767 records of which fewer than ~2 400 are INNER would be deeper than the LDS stack allows), but the
-    launcher instantiates it: SRT_WIDE_REFS=1 sends the small scenes through it so that every instantiated variant has run against
-    the CPU restatement."""
-    monkeypatch.setenv("SRT_WIDE_REFS", "1")
+    launcher instantiates it: the wide_refs test knob sends the small scenes through it so that every instantiated variant has run
+    against the CPU restatement."""
+    gpu.set_test_knobs(wide_refs=True)
     scene = srt.Scene.builtin(sid, 0).build_bvh(mode, 1984)
-    cam = scene.default_camera(W, H)
-    out = srt.render_image(scene, cam, W, H, spp, depth, renderer=gpu, count_traversal=count_traversal)
-    plan = gpu.launch_plan()
-    assert not plan["narrow_refs"]
-    assert plan["all_cached"] == (sid != 100)      # (scene 100's 4 802-triangle tree no longer fits LDS with 56-byte records and 4-byte stack slots)
-    ref = oracle_scene_for(orc, scene, mode).render(cam, W, H, spp, depth)
-    _assert_render_matches(out, ref, "scene %d, wide references" % sid, count_traversal, scene.n_tris)
+    try:
+        cam = scene.default_camera(W, H)
+        out = srt.render_image(scene, cam, W, H, spp, depth, renderer=gpu, count_traversal=count_traversal)
+        plan = gpu.launch_plan()
+        assert not plan["narrow_refs"] and plan["test_knobs"]["wide_refs"] and not plan["test_knobs"]["from_env"]
+        assert plan["all_cached"] == (sid != 100)      # (scene 100's 4 802-triangle tree no longer fits LDS with 56-byte records and 4-byte stack slots)
+        ref = oracle_scene_for(orc, scene, mode).render(cam, W, H, spp, depth)
+        _assert_render_matches(out, ref, "scene %d, wide references" % sid, count_traversal, scene.n_tris)
+    finally:
+        gpu.set_test_knobs()
+        gpu.upload_scene(scene)
 
 
 @pytest.mark.parametrize("count_traversal", VARIANTS)
@@ -886,34 +983,7 @@ def test_random_scenes_fuzz(srt, gpu, orc, seed, count_traversal):
     """Random triangle soups with random materials, cameras and builders (both BVH builders, lens on / off, thin and
     axis-aligned triangles, shared edges and vertices so that exact t ties occur -- Q11): GPU == oracle bit for bit,
     work counters included."""
-    rng = np.random.default_rng(1000 + seed)
-    n = int(rng.integers(3, 260))
-    tris, mats = [], []
-    n_mats = int(rng.integers(1, 12))
-    for k in range(n_mats):
-        mtype = int(rng.choice([0, 0, 0, 1, 1, 2, 4, 6]))
-        grey = float(rng.choice([0.0, 0.3, 0.5, 0.73, 1.0]))
-        mats.append((mtype, (grey, grey, grey), float(rng.uniform(0, 0.6)), float(rng.uniform(0.5, 3.0))))
-    verts = rng.uniform(-5, 5, (max(4, n // 2), 3)).astype(np.float32)
-    lattice = rng.random(verts.shape[0]) < 0.3
-    verts[lattice] = np.round(verts[lattice])          # some vertices on lattice points: coplanar / axis-aligned coincidences
-    for k in range(n):
-        if rng.random() < 0.6:          # triangles that share vertices (a mesh-like soup: shared edges)
-            i0, i1, i2 = rng.choice(verts.shape[0], 3, replace=False)
-            v0, v1, v2 = verts[i0], verts[i1], verts[i2]
-        else:
-            c = rng.uniform(-5, 5, 3)
-            v0, v1, v2 = (c + rng.normal(0, rng.choice([0.01, 0.5, 2.0]), 3) for _ in range(3))
-        if rng.random() < 0.15:         # axis-aligned: exercises the aa_plane projection choice (tri.cu:66-77)
-            ax = int(rng.integers(0, 3)); v0 = np.array(v0); v1 = np.array(v1); v2 = np.array(v2)
-            v1[ax] = v0[ax]; v2[ax] = v0[ax]
-        tris.append((tuple(float(x) for x in v0), tuple(float(x) for x in v1), tuple(float(x) for x in v2), int(rng.integers(0, n_mats)), int(rng.choice([0, 0, 1, 2, 3]))))
-    bg = float(rng.choice([0.5, 1.0, 0.5, 0.0]))
-    mode = int(rng.integers(0, 2))
-    scene = _custom_scene(srt, tris, mats, (bg, bg, bg)).build_bvh(mode, 1984)
-    W, H, spp, depth = int(rng.integers(9, 70)), int(rng.integers(9, 50)), int(rng.integers(1, 7)), int(rng.integers(1, 17))
-    cam = srt.camera_init(W, H, float(rng.uniform(20, 90)), tuple(rng.uniform(-12, 12, 3)), tuple(rng.uniform(-2, 2, 3)),
-                          defocus_angle=float(rng.choice([0.0, 0.0, 1.5])), focus_dist=float(rng.uniform(5, 15)))
+    scene, cam, W, H, spp, depth, mode, n = fuzz_case(srt, seed)
     out = srt.render_image(scene, cam, W, H, spp, depth, renderer=gpu, count_traversal=count_traversal)
     ref = oracle_scene_for(orc, scene, mode).render(cam, W, H, spp, depth)
     assert_planes_equal(out["xyz"], ref["xyz"], "seed %d XYZ" % seed)

@@ -110,7 +110,7 @@ def test_cli_driver_two_and_three_ranks_mock_transport(srt, tmp_path):
     def run(title, extra, env=None):
         subprocess.check_call([exe] + base + ["-t", title] + extra, cwd=str(tmp_path), timeout=180, env=env)
         return (tmp_path / "renders" / (title + ".bmp")).read_bytes()
-    env = dict(os.environ, SRT_RCCL_LIB=mock, SRT_COMM_TEST_SAME_DEVICE="1")
+    env = dict(os.environ, SRT_RCCL_LIB=mock, SRT_COMM_TEST_SAME_DEVICE="1", SRT_TEST_KNOBS="1")
     for chunks in ([], ["-xc", "40", "-yc", "24"]):
         one = run("one" + str(len(chunks)), chunks)
         assert one[:2] == b"BM" and len(one) == 54 + 96 * 72 * 3 and any(one[54:])

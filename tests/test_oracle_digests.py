@@ -1,0 +1,42 @@
+"""Frozen outputs of the CPU oracle: tests/golden/oracle_digests.json holds sha256 digests of the nine output planes
+and the ray counts of eight small workloads, written by tests/golden/make_oracle_digests.py.  The CPU test re-derives them from the
+oracle; the GPU test holds the HIP path to the SAME committed digests -- so an edit that moves product and oracle together (both
+restate D1 / D3 / no-FMA separately) turns a test red.  A drift guard, not parity evidence against the reference."""
+import json
+import os
+
+import pytest
+
+from helpers import digest_of_render, digest_workloads, oracle_scene_for
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = json.load(open(os.path.join(ROOT, "tests", "golden", "oracle_digests.json")))
+NAMES = sorted(k for k in GOLDEN if not k.startswith("_"))
+
+
+def _strip(entry):
+    return {k: v for k, v in entry.items() if k not in ("width", "height", "spp", "depth", "tris", "builder")}
+
+
+def test_golden_file_is_complete():
+    assert len(NAMES) == 8 and "prism_64x64_16spp_d8" in NAMES and "cfg1_cornell_256x256_16spp_d8" in NAMES
+    for n in NAMES:
+        assert GOLDEN[n]["rays"] >= GOLDEN[n]["paths"] > 0 and all(len(GOLDEN[n][p]) == 64 for p in ("fb_r", "srgb_g", "xyz_z"))
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_oracle_reproduces_its_frozen_digests(srt, orc, name):
+    scene, cam, W, H, spp, depth, mode = digest_workloads(srt)[name]
+    ref = oracle_scene_for(orc, scene, mode).render(cam, W, H, spp, depth)
+    assert digest_of_render(ref) == _strip(GOLDEN[name]), name
+    assert (W, H, spp, depth, scene.n_tris) == tuple(GOLDEN[name][k] for k in ("width", "height", "spp", "depth", "tris"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("count_traversal", [False, True])
+@pytest.mark.parametrize("name", NAMES)
+def test_hip_path_matches_the_frozen_digests(srt, gpu, name, count_traversal):
+    """the HIP path (production and instrumented kernel builds) against the committed digests -- no oracle call in this test"""
+    scene, cam, W, H, spp, depth, _ = digest_workloads(srt)[name]
+    out = srt.render_image(scene, cam, W, H, spp, depth, renderer=gpu, count_traversal=count_traversal)
+    assert digest_of_render(out) == _strip(GOLDEN[name]), name

@@ -11,7 +11,10 @@ NAMES = {0: "v_add_f32 x8 independent", 1: "v_pk_mul_f32 x8 independent", 2: "v_
          7: "ds_read_b64 lane-linear (+ lgkmcnt(0) per 8)", 8: "ds_read_b64 random 16 B records (+ lgkmcnt(0) per 8)", 9: "v_max3_f32 x8",
          10: "v_add_f32 x8, 26 of 64 lanes enabled",
          11: "buffer_load_dwordx4 x4 random 64 B records (16 MB table), 64 lanes", 12: "... 16 lanes, contiguous (4 full quads)",
-         13: "... 16 lanes, one per quad", 14: "... 32 lanes, contiguous", 15: "... 32 lanes, two per quad"}
+         13: "... 16 lanes, one per quad", 14: "... 32 lanes, contiguous", 15: "... 32 lanes, two per quad",
+         16: "buffer_load_dword x4 (same record offsets), 64 lanes", 17: "buffer_load_dwordx2 x4, 64 lanes", 18: "buffer_load_dwordx3 x4, 64 lanes",
+         19: "buffer_load_dword x4, 16 lanes", 20: "buffer_load_dwordx2 x4, 16 lanes", 21: "buffer_load_dwordx3 x4, 16 lanes",
+         22: "3 x dwordx4 + 1 x dword (52-byte record), 16 lanes"}
 ap = argparse.ArgumentParser()
 ap.add_argument("--iters", type=int, default=40000)
 ap.add_argument("--out", default=None)
@@ -19,7 +22,7 @@ a = ap.parse_args()
 r = srt.Renderer(0)
 rows = []
 ap2 = a
-for kind in (range(16) if not os.environ.get('CALIB_KINDS') else [int(x) for x in os.environ['CALIB_KINDS'].split(',')]):
+for kind in (range(len(NAMES)) if not os.environ.get('CALIB_KINDS') else [int(x) for x in os.environ['CALIB_KINDS'].split(',')]):
     for w in (1, 2, 4):
         res = r.calibrate(kind, w, a.iters if kind < 11 else max(1, a.iters // 40))
         res["name"] = NAMES[kind]

@@ -9,7 +9,7 @@ if [ "${1:-A}" = "A" ]; then
   python -m pytest tests -m gpu -q > $O/gpu_tests.log 2>&1; echo "gpu tests rc=$?"; tail -2 $O/gpu_tests.log
   bash tools/profile_round.sh $TAG > $O/profile_round.log 2>&1; cp -r gpurun_out/prof_$TAG $O/prof; tail -4 $O/profile_round.log
   python bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "bench rc=$?"
-  SRT_RCCL_LIB=$PWD/tests/cpp/_build/libmock_rccl.so SRT_COMM_TEST_SAME_DEVICE=1 python bench.py --gpus 2 --steps 2 --warmup 1 --no-cpu-baseline --no-calibration --cfg5-spp 64 > $O/bench_gpus2_rehearsal.json 2> $O/bench_gpus2_rehearsal.err; echo "bench --gpus 2 (rehearsal, one GPU, test transport) rc=$?"
+  SRT_RCCL_LIB=$PWD/tests/cpp/_build/libmock_rccl.so SRT_COMM_TEST_SAME_DEVICE=1 SRT_TEST_KNOBS=1 python bench.py --gpus 2 --steps 2 --warmup 1 --no-cpu-baseline --no-calibration --cfg5-spp 64 > $O/bench_gpus2_rehearsal.json 2> $O/bench_gpus2_rehearsal.err; echo "bench --gpus 2 (rehearsal, one GPU, test transport) rc=$?"
   python tools/diag.py --spp 64 > $O/diag_cfg3_64spp.json 2>&1
   bash tools/pmc_passes.sh $O/pmc_cfg3 > $O/pmc_cfg3.log 2>&1
   python tools/pmc_to_lane_ops.py $O/pmc_cfg3 "$TAG" 100 $O/lane_ops_per_ray.json > $O/lane_ops_cfg3.txt 2>&1; head -14 $O/lane_ops_cfg3.txt

@@ -6,4 +6,4 @@ for W in 1 2 3 4 8; do
   done
 done
 python tools/chain.py 2>/dev/null | grep "most expensive"
-for p in 64 32 16 8 4 2 1; do SRT_DEBUG_LANE_LIMIT=$p timeout -k 10 100 python tools/lone_tile.py ${TILE_ARGS:-} 2>&1 | grep lane_limit; done
+for p in 64 32 16 8 4 2 1; do SRT_TEST_KNOBS=1 SRT_DEBUG_LANE_LIMIT=$p timeout -k 10 100 python tools/lone_tile.py ${TILE_ARGS:-} 2>&1 | grep lane_limit; done
