@@ -620,10 +620,10 @@ def kernel_tie(renderer, entry, lib_path, tree=None):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import kernel_id
     plan = renderer.launch_plan()
-    nr, ac = int(plan["narrow_refs"]), int(plan["all_cached"])
-    variant = "render_kernel<0,%d,%d>" % (nr, ac)
-    code_hash, code_note = kernel_id.code_hash(lib_path, nr, ac)
-    isa_hash, isa_note = kernel_id.isa_hash(nr, ac)
+    nr, ac, pr = int(plan["narrow_refs"]), int(plan["all_cached"]), int(plan.get("paired", False))
+    variant = kernel_id.variant_name(nr, ac, pr)
+    code_hash, code_note = kernel_id.code_hash(lib_path, nr, ac, pr)
+    isa_hash, isa_note = kernel_id.isa_hash(nr, ac, pr)
     hashes = {"code_sha256": code_hash, "isa_listing_sha256": isa_hash}
     tie = None
     if entry is not None:

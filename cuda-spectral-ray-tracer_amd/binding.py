@@ -79,6 +79,7 @@ PROTOTYPES = {
     "srt_scene_build_bvh": (_i, [_vp, _i, _u64]),
     "srt_scene_order_children": (_i, [_vp, _fp]),
     "srt_scene_optimise_bvh": (_i, [_vp, C.c_int]),
+    "srt_scene_is_paired": (_i, [_vp]),
     "srt_scene_node_count": (_sz, [_vp]),
     "srt_scene_bvh_depth": (_i, [_vp]),
     "srt_scene_get_bvh": (_i, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), _fp]),
@@ -88,6 +89,7 @@ PROTOTYPES = {
     "srt_upload_scene": (_i, [_vp, _vp]),
     "srt_set_camera": (_i, [_vp, C.POINTER(CameraData)]),
     "srt_launch_plan": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
+    "srt_launch_paired": (_i, [_vp, C.POINTER(_i)]),
     "srt_set_test_knobs": (_i, [_vp, _i, _i, _u32]),
     "srt_get_test_knobs": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_u32), C.POINTER(_i)]),
     "srt_launch_lds_bytes": (_i, [_vp, C.POINTER(_sz)]),

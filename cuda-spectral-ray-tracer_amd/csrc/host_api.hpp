@@ -14,6 +14,7 @@
 #pragma once
 #include <stdint.h>
 
+#include <algorithm>
 #include <atomic>
 #include <cmath>
 #include <iostream>
@@ -136,7 +137,7 @@ public:
     // Tree tuning for a THROUGHPUT-bound render of the whole image on n_gpus devices (no reference counterpart: the tree is an
     // input of bvh::hit, bvh/bvh.cu:98-166): when a rank's launch has at least 6 pixels per persistent lane, the
     // SAH tree is post-optimised by reinsertion (up to 8 192 triangles) and its child order is measured on one instrumented
-    // probe frame of the scene's camera at full size, 1 sample per pixel (srt_order_children_by_profile, which undoes itself when
+    // probe frame of the scene's camera at a quarter of the size, 8 samples per pixel (srt_order_children_by_profile, which undoes itself when
     // the probe frame did not get cheaper).  Launches with fewer pixels per lane are bound by their longest pixel and keep the
     // tree as built.  Call before the renderer is created (it uploads the scene).  Returns what was done, for the log.
     std::string tune_tree_for_throughput(uint bounce_limit, int device = 0, int n_gpus = 1) {
@@ -150,11 +151,27 @@ public:
             const double per_lane = (double)xr * yr / (double)(n_gpus < 1 ? 1 : n_gpus) / (lanes > 0 ? lanes : 1.0);
             if (per_lane >= 6.0) {
                 what = "";
-                if (srt_scene_tri_count(s) <= 8192 && srt_scene_optimise_bvh(s, 3) == SRT_OK) what = "3 reinsertion passes; ";
+                if (srt_scene_tri_count(s) <= 8192) {
+                    int resident = 0, still = 0;
+                    srt_launch_plan(probe, nullptr, nullptr, &resident, nullptr);
+                    if (srt_scene_optimise_bvh(s, 3) == SRT_OK && srt_upload_scene(probe, s) == SRT_OK &&
+                        srt_launch_plan(probe, nullptr, nullptr, &still, nullptr) == SRT_OK) {
+                        if (resident && !still) {      // (a deeper tree needs deeper LDS stacks: it no longer fits LDS -- not worth it)
+                            srt_scene_build_bvh(s, SRT_BVH_SAH, SRT_DEFAULT_SEED);
+                            what = "reinsertion undone (the deeper tree would no longer be LDS resident); ";
+                        } else what = "3 reinsertion passes; ";
+                    }
+                }
+                // ONE probe recipe for every front end (bench.py / the Python binding's profile_child_order use the same): the scene's
+                // camera at a quarter of the frame's size (at least 32 x 32), 8 samples per pixel, nodes with at least 16 deciding rays --
+                // so srt_render --sah and bench.py traverse the same tree for the same workload
+                const int pw = std::max(xr / 4, 32), ph = std::max(yr / 4, 32);
+                srt_camera_data probe_cam{};
                 uint32_t swapped = 0;
-                if (srt_set_camera(probe, &cam_data) == SRT_OK &&
-                    srt_order_children_by_profile(probe, s, (uint32_t)xr, (uint32_t)yr, 1, bounce_limit, 16, &swapped) == SRT_OK)
-                    what += swapped ? "child order profiled: " + std::to_string(swapped) + " nodes swapped" : "builder's child order kept";
+                if (srt_scene_default_camera(s, pw, ph, &probe_cam) == SRT_OK && srt_set_camera(probe, &probe_cam) == SRT_OK &&
+                    srt_order_children_by_profile(probe, s, (uint32_t)pw, (uint32_t)ph, 8, bounce_limit, 16, &swapped) == SRT_OK)
+                    what += (swapped ? "child order profiled (" + std::to_string(pw) + "x" + std::to_string(ph) + " x 8 spp probe): " + std::to_string(swapped) + " nodes swapped"
+                                     : std::string("builder's child order kept"));
                 else what += std::string("child order not profiled: ") + srt_last_error(probe);
             } else what = "tree as built (chain-bound launch: fewer than 6 pixels per lane)";
         }

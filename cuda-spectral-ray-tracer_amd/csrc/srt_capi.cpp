@@ -27,6 +27,7 @@ struct srt_ctx {
     // scene images in HBM
     float *d_nodes = nullptr, *d_fringe = nullptr, *d_tris = nullptr, *d_mat_sd = nullptr, *d_mat_par = nullptr, *d_shade = nullptr, *d_cmf = nullptr;
     int root_ref = 0, stack_depth = 1, n_inner = 0, n_records = 0;
+    bool paired = false;               // the uploaded tree has no node with exactly one leaf child (srt_scene_is_paired)
     uint32_t fringe_stride = 96;       // bytes between FRINGE records in d_fringe
     uint32_t n_tris = 0;
     uint32_t n_materials = 0;
@@ -139,6 +140,7 @@ void fill_params(const srt_ctx *c, RenderParams &p) {
     p.root_ref = c->root_ref; p.stack_depth = c->stack_depth; p.n_materials = c->n_materials;
     p.n_inner = c->n_inner; p.n_cached = 0;   // n_cached is set by the launcher
     p.n_tris = c->n_tris; p.n_records = c->n_records; p.fringe_stride = c->fringe_stride;
+    p.paired = c->paired ? 1u : 0u;
     for (int k = 0; k < 3; k++) {
         p.du[k] = c->cam.pixel_delta_u[k]; p.dv[k] = c->cam.pixel_delta_v[k]; p.p00[k] = c->cam.pixel00_loc[k];
         p.center[k] = c->cam.camera_center[k]; p.disk_u[k] = c->cam.defocus_disk_u[k]; p.disk_v[k] = c->cam.defocus_disk_v[k];
@@ -249,6 +251,7 @@ int srt_upload_scene(srt_ctx *c, const srt_scene *s) {
     if ((rc = upload(c, &c->d_shade, f.shade)) != SRT_OK) return rc;
     c->root_ref = f.root_ref; c->stack_depth = f.stack_depth; c->n_materials = (uint32_t)s->mats.size();
     c->n_inner = f.n_inner; c->n_records = f.n_records; c->n_tris = (uint32_t)s->raw.size();
+    c->paired = tree_is_paired(*s);
     c->scene_ready = true;
     return SRT_OK;
 }
@@ -268,6 +271,14 @@ int srt_launch_plan(const srt_ctx *c, int *waves_per_cu, int *n_cached, int *all
     if (n_cached) *n_cached = plan.n_cached;
     if (all_cached) *all_cached = plan.all_cached ? 1 : 0;
     if (narrow_refs) *narrow_refs = render_narrow_refs(c->n_records, c->knobs) ? 1 : 0;
+    return SRT_OK;
+}
+
+int srt_launch_paired(const srt_ctx *c, int *paired) {
+    if (!c || !c->scene_ready || !paired) return fail(nullptr, SRT_ERR_INVALID, "srt_launch_paired: no scene uploaded / null argument");
+    LaunchPlan plan;
+    render_launch_plan(c->stack_depth, c->n_records, c->n_inner, c->knobs, plan);
+    *paired = render_paired_variant(c->paired, render_narrow_refs(c->n_records, c->knobs), plan.all_cached) ? 1 : 0;
     return SRT_OK;
 }
 

@@ -677,7 +677,10 @@ __device__ __forceinline__ void trav_fringe_fetch(FringeFetch &ff, const Trav &t
     // a FRINGE visit never pushes (at most one child is internal), so it only needs the entry a pop would bring up
     ff.below = NARROW ? (int)*(lds_i16 *)(uintptr_t)tv.sp : *(lds_i32 *)(uintptr_t)tv.sp;
 }
-template <bool COUNT, bool NARROW>
+// PAIRED: the tree has no node with exactly ONE leaf child (srt_scene_is_paired: the SAH builder's even splits), so every FRINGE record
+// holds two triangles: the slab test of "the internal child" and the descent into it -- a fifth of the visit's instructions, needed by
+// 5-9 % of the FRINGE visits of an unpaired tree -- are not compiled in, and the visit always ends with a pop.
+template <bool COUNT, bool NARROW, bool PAIRED = false>
 __device__ __forceinline__ void trav_fringe_compute(const FringeFetch &ff, Trav &tv, V3 o, V3 d, V3 inv, TravStats &ts) {
     const f4v q0 = ff.q0, q1 = ff.q1, q2 = ff.q2, q3 = ff.q3, q4 = ff.q4, q5 = ff.q5;
     const int below = ff.below;
@@ -685,15 +688,15 @@ __device__ __forceinline__ void trav_fringe_compute(const FringeFetch &ff, Trav 
     const f2 w6 = mk2(q3.x, q3.y), w7 = mk2(q3.z, q3.w), w8 = mk2(q4.x, q4.y), w9 = mk2(q4.z, q4.w);
     const uint32_t fl = __float_as_uint(q5.x), fr = __float_as_uint(q5.y);
     const int lref = (int)__float_as_uint(q5.z), rref = (int)__float_as_uint(q5.w);
-    const bool leaf_l = lref < 0, leaf_r = rref < 0;
+    const bool leaf_l = PAIRED || lref < 0, leaf_r = PAIRED || rref < 0;
     if (COUNT) { ts.n_iters++; ts.n_tri += (leaf_l ? 1u : 0u) + (leaf_r ? 1u : 0u); ts.n_box += (leaf_l ? 0u : 1u) + (leaf_r ? 0u : 1u); }
 
     // ---- the box of the internal child (words 0-5 = xmin xmax ymin ymax zmin zmax of its block).  A FRINGE record has at
     // least one leaf child, so at most ONE child has a box: one scalar slab test on the right child's words when the right
     // child is internal, on the left child's otherwise (both leaves: the result is ignored) -- half the arithmetic of the
     // paired test of an INNER record.  aabb::hit (aabb.cu:7-40) as in box_pair: e = max(tmin, t0x, t0y, t0z), m = min(t1x, t1y, t1z).
-    float e_box, m_box;
-    {
+    float e_box = 0.f, m_box = 0.f;
+    if (!PAIRED) {
         const bool int_r = !leaf_r;
         const float xlo = int_r ? w0.y : w0.x, xhi = int_r ? w1.y : w1.x, ylo = int_r ? w2.y : w2.x, yhi = int_r ? w3.y : w3.x;
         const float zlo = int_r ? w4.y : w4.x, zhi = int_r ? w5.y : w5.x;
@@ -742,21 +745,27 @@ __device__ __forceinline__ void trav_fringe_compute(const FringeFetch &ff, Trav 
     const float c2 = hit_r ? t.y : c1;
     // the one box: an internal LEFT child is tested with c0 (before anything on the right), an internal RIGHT child with c1 (after
     // the left leaf's hit, if any)
-    const bool pass = !(fminf(leaf_r ? c0 : c1, m_box) <= e_box);
     tv.c = c2;
     tv.hit = hit_r ? ~rref : (hit_l ? ~lref : tv.hit);
+    const int top = tv.top;
+    if (PAIRED) {      // two leaves: nothing to descend into (bvh.cu:154-160: neither child is traversable -> pop)
+        tv.node = top;
+        tv.top = below;
+        tv.sp += (uint32_t)(-kStackStride<NARROW>);
+        return;
+    }
+    const bool pass = !(fminf(leaf_r ? c0 : c1, m_box) <= e_box);
     // bvh.cu:154-160 with at most one traversable child: descend into it, or pop; never a push
     const bool go = !(leaf_l & leaf_r) & pass;
-    const int top = tv.top;
     tv.node = go ? (leaf_r ? lref : rref) : top;
     tv.top = go ? top : below;
     tv.sp += (uint32_t)(go ? 0 : -kStackStride<NARROW>);
 }
-template <bool COUNT, bool NARROW>
+template <bool COUNT, bool NARROW, bool PAIRED = false>
 __device__ __forceinline__ void trav_step_fringe(Trav &tv, const NodeSrc &ns, V3 o, V3 d, V3 inv, const StackRef &stack, TravStats &ts) {
     FringeFetch ff;
     trav_fringe_fetch<NARROW>(ff, tv, ns, stack);
-    trav_fringe_compute<COUNT, NARROW>(ff, tv, o, d, inv, ts);
+    trav_fringe_compute<COUNT, NARROW, PAIRED>(ff, tv, o, d, inv, ts);
 }
 
 

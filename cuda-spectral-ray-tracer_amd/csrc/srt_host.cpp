@@ -208,6 +208,14 @@ int build_bvh_reference(srt_scene &s, uint64_t seed) {
 // decreasing area, `passes` times.
 // Leaves stay one triangle each; only the topology above them changes.  The tree is an input of the traversal: results do not
 // depend on it (except where two triangles tie exactly in t, Q11 -- and the CPU checker walks the same tree).
+// every internal node has two leaf children or none (what build_bvh_sah's even splits produce for an even triangle count)
+bool tree_is_paired(const srt_scene &s) {
+    if (s.nodes.size() < 3) return false;
+    for (const BvhNode &nd : s.nodes)
+        if (nd.prim < 0 && (s.nodes[nd.left].prim >= 0) != (s.nodes[nd.right].prim >= 0)) return false;
+    return true;
+}
+
 static void optimise_bvh_by_reinsertion(srt_scene &s, int passes) {
     const int32_t n = (int32_t)s.nodes.size();
     if (passes <= 0 || n < 7) return;
@@ -277,6 +285,9 @@ static void optimise_bvh_by_reinsertion(srt_scene &s, int passes) {
     // the same V on cfg 3's scene, another -1.3 % (SRT_BVH_FRINGE_WEIGHT overrides; 1 = plain surface area).
     const double cf = getenv("SRT_BVH_FRINGE_WEIGHT") ? std::max(1.0, atof(getenv("SRT_BVH_FRINGE_WEIGHT"))) : 2.5;
     auto is_leaf = [&](int32_t k) { return s.nodes[k].prim >= 0; };
+    // A PAIRED tree (every internal node has two leaf children or none: build_bvh_sah's even splits) stays paired: only internal
+    // subtrees move (their triangle count is even) and only next to internal nodes -- a leaf is never taken out of, or put into, a pair.
+    const bool paired = tree_is_paired(s);
     auto wgt = [&](int32_t k) { return (!is_leaf(k) && (is_leaf(s.nodes[k].left) || is_leaf(s.nodes[k].right))) ? cf : 1.0; };
     std::vector<int32_t> todo(n);
     for (int pass = 0; pass < passes; pass++) {
@@ -285,6 +296,7 @@ static void optimise_bvh_by_reinsertion(srt_scene &s, int passes) {
         for (int32_t N : todo) {
             const int32_t P = parent[N];
             if (P < 0 || parent[P] < 0) continue;      // the root and its children stay (the parent node is re-used as the new parent)
+            if (paired && is_leaf(N)) continue;
             const int32_t G = parent[P];
             const int32_t S = s.nodes[P].left == N ? s.nodes[P].right : s.nodes[P].left;
             replace_child(G, P, S);                    // take N (and P) out
@@ -301,6 +313,7 @@ static void optimise_bvh_by_reinsertion(srt_scene &s, int passes) {
                 const double credit_max = cf > 1.0 && gx >= 0 ? (cf - 1.0) * area[gx] : 0.0;
                 if (c.induced + a_n - credit_max >= best_cost) break;      // every remaining position costs at least that
                 const BvhNode &x = s.nodes[c.node];
+                if (paired && x.prim >= 0) continue;      // (not a position: a leaf stays with its partner)
                 float u[6];
                 for (int a = 0; a < 3; a++) { u[2 * a] = fminf(x.box[2 * a], nb[2 * a]); u[2 * a + 1] = fmaxf(x.box[2 * a + 1], nb[2 * a + 1]); }
                 const double ua = area_of(u);
@@ -382,6 +395,12 @@ int build_bvh_sah(srt_scene &s) {
     const double kAlpha = getenv("SRT_SAH_ALPHA") ? atof(getenv("SRT_SAH_ALPHA")) : 1.0;
     auto weight = [&](double n_tris) { return kAlpha == 1.0 ? n_tris : (kAlpha < 0 ? n_tris * (1.0 + std::log2(n_tris)) : std::pow(n_tris, kAlpha)); };
     const size_t kSweepMax = getenv("SRT_SAH_SWEEP") ? (size_t)std::max(0, atoi(getenv("SRT_SAH_SWEEP"))) : 8192;   // exact sweep below this span
+    // PAIRED trees (round 5).  A node with ONE leaf child costs every FRINGE visit of the render kernel a box test it needs for
+    // those nodes alone (a fifth of the visit's instructions; 5-9 % of the FRINGE visits on the benchmark scene go there).  With an
+    // even triangle count every span is cut into two EVEN halves, so every internal node has two leaf children or none, and the
+    // launcher picks the kernel variant without that box test (render_kernel<.., PAIRED>).  An odd span (odd triangle count) splits
+    // freely: such a tree keeps one leaf + subtree node per odd level and the general variant.  SRT_SAH_EVEN=0: round 4's builder.
+    const bool kEven = !(getenv("SRT_SAH_EVEN") && atoi(getenv("SRT_SAH_EVEN")) == 0);
     while (!stack.empty()) {
         const Span cur = stack.back();
         stack.pop_back();
@@ -432,6 +451,7 @@ int build_bvh_sah(srt_scene &s) {
                     acc.reset();
                     for (size_t k = 0; k + 1 < span; k++) {
                         acc.grow(s.rec[tmp[k]].box);
+                        if (kEven && span % 2 == 0 && (k + 1) % 2 != 0) continue;      // (both halves even)
                         const double cost = acc.area() * weight((double)(k + 1)) + right_area[k + 1] * weight((double)(span - k - 1));
                         if (cost < sweep_cost) { sweep_cost = cost; sweep_mid = k + 1; best_order = tmp; }
                     }
@@ -452,10 +472,19 @@ int build_bvh_sah(srt_scene &s) {
                     return b <= best_bin;
                 });
                 mid = (size_t)(it - order.begin());
+                if (kEven && span % 2 == 0 && (mid - cur.start) % 2 != 0 && mid > cur.start && mid < cur.end) {
+                    // binned split of an even span into two odd halves: move the right half's triangle nearest to the plane across
+                    auto nearest = std::min_element(order.begin() + mid, order.begin() + cur.end,
+                                                    [&](int32_t a, int32_t b) { return centroid(a, best_axis) < centroid(b, best_axis); });
+                    std::iter_swap(order.begin() + mid, nearest);
+                    mid++;
+                    if (mid == cur.end) mid -= 2;      // (the right half held one triangle: take one from the left instead)
+                }
             }
             if (best_axis < 0 || mid == cur.start || mid == cur.end) {
                 // coincident centroids: median split on the widest box axis keeps the tree balanced
                 mid = cur.start + span / 2;
+                if (kEven && span % 2 == 0 && (span / 2) % 2 != 0) mid++;      // (span 4k + 2: halves 2k + 2 and 2k)
                 std::nth_element(order.begin() + cur.start, order.begin() + mid, order.begin() + cur.end,
                                  [&](int32_t a, int32_t b) { return cx[a] < cx[b]; });
             }
@@ -600,7 +629,20 @@ int flatten_scene(const srt_scene &s, FlatScene &out) {
     }
     out.root_ref = child_ref(s.root);
     out.n_records = (int)pre.size();
-    out.stack_depth = std::max(1, s.depth);
+    // Entries the traversal stack can hold at once: a push happens only at an INNER record (both children internal, bvh.cu:154-160:
+    // "push right iff both"), one per INNER node on the way down, so the bound is the largest number of INNER nodes on a root-to-leaf
+    // path -- at least one less than the tree's depth (the last internal level always has a leaf child).  Round 4 sized the LDS stacks
+    // by the depth; one slot per wave is 2 KB of LDS = 39 more cached records, which is what decides whether a 4 802-triangle paired
+    // tree (2 400 INNER records) of depth 17 is LDS resident.
+    {
+        std::vector<int> inner_path(s.nodes.size(), 0);
+        for (size_t k = s.nodes.size(); k-- > 0;) {      // (children have larger indices than their parent)
+            const BvhNode &nd = s.nodes[k];
+            if (nd.prim >= 0) continue;
+            inner_path[k] = (is_inner((int32_t)k) ? 1 : 0) + std::max(inner_path[nd.left], inner_path[nd.right]);
+        }
+        out.stack_depth = std::max(1, s.root >= 0 ? inner_path[s.root] : 1);
+    }
 
     // spectra as (s[k], s[k+1]) pairs; material scalars
     auto pairs = [](const float *sd, float *dst) {
@@ -1377,6 +1419,7 @@ int srt_rotation_matrix(float theta, int axis, float m[9]) {
     assign_rot_matrix(theta, axis, m);
     return SRT_OK;
 }
+int srt_scene_is_paired(const srt_scene *s) { return (s && s->bvh_valid && tree_is_paired(*s)) ? 1 : 0; }
 size_t srt_scene_node_count(const srt_scene *s) { return (s && s->bvh_valid) ? s->nodes.size() : 0; }
 int srt_scene_bvh_depth(const srt_scene *s) { return (s && s->bvh_valid) ? s->depth : 0; }
 

@@ -75,6 +75,8 @@ void scene_builtin(srt_scene &s, int scene_id, uint64_t seed);
 bool scene_builtin_known(int scene_id);
 
 // GPU images of the scene (layout: srt_device.h)
+bool tree_is_paired(const srt_scene &s);      // every internal node has two leaf children or none
+
 struct FlatScene {
     std::vector<float> nodes;    // 16 floats per INNER record (both children internal)
     std::vector<float> fringe;   // 24 floats per FRINGE record (a leaf child; triangle data inline, (left, right) pairs), record index - n_inner

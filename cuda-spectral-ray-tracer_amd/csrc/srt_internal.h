@@ -36,6 +36,7 @@ struct RenderParams {
     uint32_t fringe_stride;    // bytes between two FRINGE records: 96 (packed) or 128 (one cache line each: trees served by L2)
     uint32_t n_materials;
     uint32_t n_tris;
+    uint32_t paired;           // host side only (the launcher's choice of variant): the tree has no node with exactly one leaf child
     // camera_data (rendering/rendering.cuh:28-36)
     float du[3], dv[3], p00[3];
     float defocus_angle;
@@ -106,6 +107,7 @@ hipError_t launch_calib(int kind, uint32_t n_blocks, uint32_t threads, uint32_t 
                         uint32_t n_records, hipStream_t st);
 int calib_kinds();
 bool render_narrow_refs(int n_records, const PlanKnobs &k);
+bool render_paired_variant(bool tree_is_paired, bool narrow, bool all_cached);      // does launch_render pick render_kernel<.., PAIRED = true>?
 size_t render_lds_bytes(int stack_depth, int waves_per_block, int n_cached, int n_records, const PlanKnobs &k);
 void render_launch_shape(int stack_depth, int n_records, int n_inner, const PlanKnobs &k, int &waves_per_block, int &n_cached);
 struct LaunchPlan { int waves_per_block, blocks_per_cu, waves_per_cu, waves_per_eu, n_cached; bool all_cached; };

@@ -83,6 +83,13 @@ void render_launch_plan(int stack_depth, int n_records, int n_inner, const PlanK
     lp.waves_per_cu = lp.waves_per_block * lp.blocks_per_cu;
 }
 
+#ifndef SRT_PAIRED_VARIANT
+#define SRT_PAIRED_VARIANT 1      /* 0: kernel experiments -- paired trees run the general variant too */
+#endif
+// (instantiated for the two shapes real scenes launch: 16-bit references with the whole inner tree in LDS, 32-bit references with the
+// inner tree partly in L2; the mid-size shape <.,1,0> and the test-only shape <.,0,1> run the general variant)
+bool render_paired_variant(bool tree_is_paired, bool narrow, bool all_cached) { return SRT_PAIRED_VARIANT != 0 && tree_is_paired && narrow == all_cached; }
+
 // Cost band (0 = most expensive) of the first queue row that wave w of a workgroup takes (render_kernel S3): row = band * number of
 // workgroups + workgroup.  SRT_ASSIGN_PERM picks how the bands are dealt to the waves of a workgroup: 0 in wave order, 1 transposed
 // (w % 4) * 4 + w / 4, 2 boustrophedon over groups of four (0 1 2 3 | 7 6 5 4 | 8 ...), so that the four waves w, w + 4, w + 8, w + 12
@@ -125,7 +132,8 @@ __global__ void init_rng_kernel(uint32_t *rng, uint32_t n_lanes, uint64_t seed) 
 // MODE 0: production; MODE 1: instrumented (counts V / T / utilisation); MODE 2: cost probe -- renders P.spp samples per
 // pixel from a COPY of the RNG state, writes nothing but the per-tile traversal cost used to order the pixel queue.
 // ALL_CACHED: the whole inner tree fits the LDS cache (n_cached == n_inner): the INNER step has no global fall-back path.
-template <int MODE, bool NARROW, bool ALL_CACHED>
+// PAIRED (instantiated for <., 1, 1> and <., 0, 0>): every FRINGE record holds two triangles (srt_scene_is_paired): the visit has no box test.
+template <int MODE, bool NARROW, bool ALL_CACHED, bool PAIRED>
 __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
     constexpr bool COUNT = (MODE == 1);
     constexpr bool PROBE = (MODE == 2);
@@ -590,7 +598,7 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
             while (__ballot(tv.node >= 0) != 0ull) {
                 if (tv.node >= 0) {
                     if ((uint32_t)tv.node < n_inner_u) trav_step_inner<ITERS, NARROW, ALL_CACHED>(tv, ns, ro, inv, my_stack, ts);
-                    else trav_step_fringe<ITERS, NARROW>(tv, ns, ro, rd, inv, my_stack, ts);
+                    else trav_step_fringe<ITERS, NARROW, PAIRED>(tv, ns, ro, rd, inv, my_stack, ts);
                 }
             }
             continue;
@@ -599,7 +607,7 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
             // production build: the decision below and the INNER bursts it leads to are one assembly block (inner_phase_asm,
             // srt_device.h -- the same arithmetic); only the FRINGE visits come back here
             while (inner_phase_asm(tv, ns, ro, inv, n_inner_u, n_alive, w_shade, w_fringe) != 0u) {
-                if (tv.node >= (int)n_inner_u) trav_step_fringe<ITERS, NARROW>(tv, ns, ro, rd, inv, my_stack, ts);
+                if (tv.node >= (int)n_inner_u) trav_step_fringe<ITERS, NARROW, PAIRED>(tv, ns, ro, rd, inv, my_stack, ts);
             }
         } else
         for (;;) {
@@ -618,7 +626,7 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
             const bool do_fringe = s_fr > s_in;
             if (COUNT) { ts.w_iters++; ts.w_alive += n_alive; if (do_fringe) { ts.w_fringe++; ts.l_fringe += n_fringe; } else ts.l_inner += n_trav - n_fringe; }
             if (do_fringe) {
-                if (tv.node >= (int)n_inner_u) trav_step_fringe<ITERS, NARROW>(tv, ns, ro, rd, inv, my_stack, ts);
+                if (tv.node >= (int)n_inner_u) trav_step_fringe<ITERS, NARROW, PAIRED>(tv, ns, ro, rd, inv, my_stack, ts);
                 if (COUNT) { const unsigned long long now = __builtin_amdgcn_s_memtime(); t_fringe += now - t_mark; t_mark = now; }
             } else {
                 // a short burst of inner steps between two scheduling decisions: the ballots / popcounts of the loop head
@@ -952,7 +960,7 @@ hipError_t launch_init_rng(uint32_t *rng, uint32_t n_lanes, uint64_t seed, hipSt
     return hipGetLastError();
 }
 
-template <int MODE, bool NARROW, bool ALL_CACHED>
+template <int MODE, bool NARROW, bool ALL_CACHED, bool PAIRED = false>
 static hipError_t launch_render_cached(const RenderParams &p_in, const LaunchPlan &lp, const PlanKnobs &knobs, uint32_t n_cu, hipStream_t st, uint32_t *waves_launched) {
     RenderParams p = p_in;
     int wpb = lp.waves_per_block;
@@ -967,7 +975,7 @@ static hipError_t launch_render_cached(const RenderParams &p_in, const LaunchPla
     // per launch, not once per process: the attribute belongs to the function ON THE CURRENT DEVICE, and one process may
     // drive several GPUs (srt_comm_init_all); the call is a host-side table update
     {
-        const hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<MODE, NARROW, ALL_CACHED>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget);
+        const hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<MODE, NARROW, ALL_CACHED, PAIRED>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget);
         if (ae != hipSuccess) return ae;
     }
     // persistent waves: fill every CU (waves_per_cu at this build's register budget), never more waves than queue rows
@@ -975,7 +983,7 @@ static hipError_t launch_render_cached(const RenderParams &p_in, const LaunchPla
     if (n_waves > p.queue_rows_bound) n_waves = p.queue_rows_bound;     // (upper bound known to the host)
     const uint32_t n_blocks = (n_waves + (uint32_t)wpb - 1) / (uint32_t)wpb;
     if (waves_launched) *waves_launched = n_blocks * (uint32_t)wpb;
-    hipLaunchKernelGGL((render_kernel<MODE, NARROW, ALL_CACHED>), dim3(n_blocks), dim3(64 * wpb), lds, st, p);
+    hipLaunchKernelGGL((render_kernel<MODE, NARROW, ALL_CACHED, PAIRED>), dim3(n_blocks), dim3(64 * wpb), lds, st, p);
     return hipGetLastError();
 }
 
@@ -986,6 +994,10 @@ static hipError_t launch_render_mode(const RenderParams &p, const PlanKnobs &kno
     // (the ALL_CACHED variant reads packed 96-byte FRINGE records by a literal stride: never pick it for a scene that was uploaded
     // with padded records -- the plan can only differ from the upload's when the context's test knobs changed in between)
     if (lp.all_cached && p.fringe_stride != 96u) lp.all_cached = false;
+    // a paired tree (no node with one leaf child) that is LDS resident with 16-bit references runs the variant without the FRINGE box test
+    if (render_paired_variant(p.paired != 0u, NARROW, lp.all_cached))
+        return NARROW ? launch_render_cached<MODE, true, true, true>(p, lp, knobs, n_cu, st, waves_launched)
+                      : launch_render_cached<MODE, false, false, true>(p, lp, knobs, n_cu, st, waves_launched);
     return lp.all_cached ? launch_render_cached<MODE, NARROW, true>(p, lp, knobs, n_cu, st, waves_launched) : launch_render_cached<MODE, NARROW, false>(p, lp, knobs, n_cu, st, waves_launched);
 }
 

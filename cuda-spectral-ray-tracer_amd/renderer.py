@@ -47,10 +47,12 @@ class Renderer:
         self._ck(B.lib().srt_upload_scene(self._h, scene.handle))
 
     def launch_plan(self):
-        """dict(waves_per_cu, n_cached, all_cached, narrow_refs) of the uploaded scene's render launch"""
+        """dict(waves_per_cu, n_cached, all_cached, narrow_refs, paired) of the uploaded scene's render launch"""
         w, n, a, r = C.c_int(), C.c_int(), C.c_int(), C.c_int()
         self._ck(B.lib().srt_launch_plan(self._h, C.byref(w), C.byref(n), C.byref(a), C.byref(r)))
-        return dict(waves_per_cu=w.value, n_cached=n.value, all_cached=bool(a.value), narrow_refs=bool(r.value), test_knobs=self.test_knobs())
+        pr = C.c_int()
+        self._ck(B.lib().srt_launch_paired(self._h, C.byref(pr)))
+        return dict(waves_per_cu=w.value, n_cached=n.value, all_cached=bool(a.value), narrow_refs=bool(r.value), paired=bool(pr.value), test_knobs=self.test_knobs())
 
     def set_test_knobs(self, wide_refs=False, lds_cache_max=-1, lane_limit=0):
         """tests / tools only (srt_c_api.h): force kernel variants the plan would not pick; upload the scene again afterwards"""
@@ -302,8 +304,17 @@ def tune_tree_for_throughput(renderer, scene, width, height, bounce_limit):
     Returns a description for the record.  Deterministic: every rank arrives at the same tree."""
     notes = []
     if scene.n_tris <= 8192:
+        renderer.upload_scene(scene)
+        resident = renderer.launch_plan()["all_cached"]
         scene.optimise_bvh(3)
-        notes.append("3 reinsertion passes")
+        renderer.upload_scene(scene)
+        if resident and not renderer.launch_plan()["all_cached"]:
+            # (reinsertion may deepen the tree: deeper LDS stacks, fewer cached records -- a tree that just fitted LDS no longer does,
+            # which costs far more than the passes return)
+            scene.build_bvh(B.BVH_SAH, 1984)
+            notes.append("reinsertion undone (the deeper tree would no longer be LDS resident)")
+        else:
+            notes.append("3 reinsertion passes")
     n, (pw, ph, ps) = profile_child_order(renderer, scene, width, height, bounce_limit)
     notes.append(("child order profiled on a %dx%d x %d spp probe frame: %d nodes swapped" % (pw, ph, ps, n)) if n else
                  ("builder's child order kept (the %dx%d x %d spp probe frame was not cheaper with the profiled one)" % (pw, ph, ps)))

@@ -99,6 +99,11 @@ class Scene:
         return B.lib().srt_scene_node_count(self._h)
 
     @property
+    def is_paired(self):
+        """every internal node has two leaf children or none (SAH builder, even triangle count): the launch uses the PAIRED kernel variant"""
+        return bool(B.lib().srt_scene_is_paired(self._h))
+
+    @property
     def bvh_depth(self):
         return B.lib().srt_scene_bvh_depth(self._h)
 

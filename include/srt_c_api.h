@@ -176,6 +176,10 @@ SRT_API int srt_scene_order_children(srt_scene *s, const float eye[3]);
  * ray on average; NOT a cheaper worst pixel -- measured slower on launches bound by their longest pixel (few pixels per lane), so it
  * is a call of its own and not part of srt_scene_build_bvh.  Upload the scene afterwards. */
 SRT_API int srt_scene_optimise_bvh(srt_scene *s, int passes);
+/* 1 when every internal node of the built tree has two leaf children or none ("paired": what SRT_BVH_SAH builds for an even triangle
+ * count -- it cuts every span into two even halves -- and what srt_scene_optimise_bvh preserves).  The render launch of such a tree uses
+ * the kernel variant whose FRINGE visit carries no box test (a node with one leaf child is the only kind that needs it). */
+SRT_API int srt_scene_is_paired(const srt_scene *s);
 SRT_API size_t srt_scene_node_count(const srt_scene *s);
 SRT_API int srt_scene_bvh_depth(const srt_scene *s);
 /* Pre-order dump (same convention as the oracle): left/right = pre-order ranks or -1, prim = original
@@ -200,6 +204,9 @@ SRT_API int srt_set_camera(srt_ctx *ctx, const srt_camera_data *cam);
  * records resident in LDS, whether that is the whole inner tree (kernel variant ALL_CACHED) and whether record references fit 15
  * bits (variant NARROW).  Any pointer may be NULL. */
 SRT_API int srt_launch_plan(const srt_ctx *ctx, int *waves_per_cu, int *n_cached, int *all_cached, int *narrow_refs);
+/* 1 when the render launch of the uploaded scene uses the PAIRED kernel variant (FRINGE visit without a box test): the tree is paired
+ * (srt_scene_is_paired), fits LDS and has 16-bit references. */
+SRT_API int srt_launch_paired(const srt_ctx *ctx, int *paired);
 /* TEST KNOBS of a context (no reference counterpart; tests/ and tools/ only).  They force a launch through kernel variants the plan
  * would not pick for the scene, so that every instantiated variant is held to the oracle: wide_refs != 0 -> 32-bit child references
  * for small trees too; lds_cache_max >= 0 caps the inner records kept in LDS (0: every inner record from L2; -1: no cap);

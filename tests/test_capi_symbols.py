@@ -81,8 +81,9 @@ def test_kernel_identity_from_the_code_object(srt):
     kid = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(kid)
     hs = kid.code_hashes(srt.binding.LIB_PATH)
-    assert set(hs) == {(0, 0), (0, 1), (1, 0), (1, 1)}                      # render_kernel<0, NARROW, ALL_CACHED>
-    assert all(len(v) == 64 and int(v, 16) >= 0 for v in hs.values()) and len(set(hs.values())) == 4
+    assert set(hs) == {(0, 0), (0, 1), (1, 0), (1, 1), (1, 1, 1), (0, 0, 1)}      # render_kernel<0, NARROW, ALL_CACHED> + the PAIRED variants of <0,1,1> and <0,0,0>
+    assert all(len(v) == 64 and int(v, 16) >= 0 for v in hs.values()) and len(set(hs.values())) == 6
+    assert kid.code_hash(srt.binding.LIB_PATH, 1, 1, 1)[0] == hs[(1, 1, 1)] and kid.variant_name(1, 1, 1) == "render_kernel<0,1,1,paired>"
     h, note = kid.code_hash(srt.binding.LIB_PATH, 1, 1)
     assert h == hs[(1, 1)] and "machine code" in note
     assert kid.code_hash("/no/such/library.so", 1, 1)[0] is None

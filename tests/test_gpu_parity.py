@@ -918,6 +918,29 @@ def _assert_render_matches(out, ref, what, count_traversal, n_tris):
 
 
 @pytest.mark.parametrize("count_traversal", VARIANTS)
+@pytest.mark.parametrize("n,expect_paired", [(600, True), (601, False), (2, True), (3, False), (40000, True), (40001, False)])
+def test_paired_trees_launch_the_paired_variant_and_stay_exact(srt, gpu, orc, n, expect_paired, count_traversal):
+    """Round 5: the SAH builder cuts every even span into two even halves, so a scene with an even triangle count gets a PAIRED tree (every
+    internal node has two leaf children or none) and its launch uses render_kernel<.., PAIRED> -- FRINGE visits without the box test that only
+    a leaf + subtree node needs: <.,1,1,paired> for LDS-resident trees, <.,0,0,paired> for the 40 000-triangle soup (32-bit references,
+    inner tree partly in L2).  One more triangle: an unpaired tree, the general variant.  Both bit for bit == the oracle walking the same
+    tree, work counters included; reinsertion (srt_scene_optimise_bvh) keeps a paired tree paired."""
+    scene = _soup(srt, n, n).build_bvh(srt.BVH_SAH, 1984)
+    assert scene.is_paired == expect_paired
+    if 8 <= n <= 8192:
+        scene.optimise_bvh(2)
+        assert scene.is_paired == expect_paired
+    W, H, spp, depth = 56, 40, 3, 8
+    cam = srt.camera_init(W, H, 50.0, (0.5, 1.0, 16.0), (0.0, 0.0, 0.0), defocus_angle=0.6, focus_dist=14.0)
+    out = srt.render_image(scene, cam, W, H, spp, depth, renderer=gpu, count_traversal=count_traversal)
+    plan = gpu.launch_plan()
+    assert plan["paired"] == expect_paired, plan
+    assert plan["narrow_refs"] == plan["all_cached"] == (n < 40000)
+    ref = oracle_scene_for(orc, scene, 1).render(cam, W, H, spp, depth)
+    _assert_render_matches(out, ref, "soup of %d (paired %s)" % (n, expect_paired), count_traversal, n)
+
+
+@pytest.mark.parametrize("count_traversal", VARIANTS)
 @pytest.mark.parametrize("cap", [0, 3])
 @pytest.mark.parametrize("sid,mode,W,H,spp,depth", [SCENES[0], SCENES[2], SCENES[3], SCENES[4], SCENES[8], SCENES[9], SCENES[11]])
 def test_partly_cached_narrow_tree_forced_on_small_scenes(srt, gpu, orc, monkeypatch, sid, mode, W, H, spp, depth, cap, count_traversal):

@@ -132,7 +132,15 @@ def test_cli_driver_tunes_its_own_tree_for_throughput_bound_renders(srt, tmp_pat
         return (tmp_path / "renders" / (title + ".bmp")).read_bytes(), p.stderr.decode(errors="replace")
     big_tuned, log_tuned = run("big_tuned", 1920, {})
     big_plain, log_plain = run("big_plain", 1920, {"SRT_NO_TREE_TUNING": "1"})
-    assert "BVH: 3 reinsertion passes; child order profiled:" in log_tuned and "nodes swapped" in log_tuned
+    assert "BVH: 3 reinsertion passes; child order profiled (480x270 x 8 spp probe):" in log_tuned and "nodes swapped" in log_tuned
+    # ONE probe recipe in every front end: the Python helper bench.py uses arrives at the same tree for the same workload
+    import re
+    r = srt.Renderer(0)
+    scene = srt.Scene.builtin(100, 0).build_bvh(srt.BVH_SAH, 1984)
+    r.upload_scene(scene)
+    note = srt.tune_tree_for_throughput(r, scene, 1920, 1080, 8)
+    r.close()
+    assert re.search(r"(\d+) nodes swapped", note).group(1) == re.search(r"(\d+) nodes swapped", log_tuned).group(1), (note, log_tuned)
     assert "BVH: tree as built (SRT_NO_TREE_TUNING)" in log_plain
     a, b = np.frombuffer(big_tuned, np.uint8), np.frombuffer(big_plain, np.uint8)
     assert a.size == b.size == 54 + 1920 * 1080 * 3 and int(np.count_nonzero(a != b)) <= 64

@@ -326,3 +326,25 @@ def test_cornell_geometry_is_a_rigid_arrangement_of_the_reference_numbers(srt):
     side = np.sort(np.linalg.norm(base[:, None, :] - base[None, :, :], axis=2), axis=1)
     assert np.allclose(side[:, 1:], [[165.0, 165.0, 165.0 * np.sqrt(2.0)]] * 4, atol=2e-3)      # a 165-square
     assert np.allclose(base[:, [0, 2]].mean(axis=0), (130.0 + 82.5, 65.0 + 82.5), atol=1e-3)    # same pivot and shift as the small box
+
+
+def test_sah_builder_pairs_leaves_and_reinsertion_keeps_them_paired(srt):
+    """Round 5 (host side, no GPU): SRT_BVH_SAH on an even triangle count gives a tree in which every internal node has two leaf children
+    or none -- the exact sweep prices even split positions only, the binned path above 8 192 triangles moves one triangle across an odd
+    split -- and srt_scene_optimise_bvh moves internal subtrees only, next to internal nodes.  An odd count cannot be paired; the reference
+    builder's trees are whatever bvh.cu:206-346 makes them."""
+    import numpy as np
+    for sid, paired in ((srt.SCENE_RANDOM_SPHERES, True), (srt.SCENE_MESH100K, True), (srt.SCENE_PRISM, True), (srt.SCENE_CORNELL, True)):
+        sc = srt.Scene.builtin(sid, 0).build_bvh(srt.BVH_SAH, 1984)
+        assert sc.n_tris % 2 == 0 and sc.is_paired == paired, sid
+        left, right, prim, _ = sc.bvh()
+        leaf = prim >= 0
+        for k in np.nonzero(~leaf)[0]:
+            assert leaf[left[k]] == leaf[right[k]]
+        if sc.n_tris <= 8192:
+            d0 = sc.bvh_depth
+            sc.optimise_bvh(3)
+            assert sc.is_paired and sc.n_nodes == 2 * sc.n_tris - 1 and sc.bvh_depth <= d0 + 2
+            l2, r2, p2, _ = sc.bvh()
+            assert sorted(p2[p2 >= 0].tolist()) == list(range(sc.n_tris))          # every triangle still in exactly one leaf
+    assert not srt.Scene.builtin(srt.SCENE_PRISM, 0).build_bvh(srt.BVH_REFERENCE, 1984).is_paired or True   # (no claim about the reference builder)

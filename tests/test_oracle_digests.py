@@ -40,3 +40,19 @@ def test_hip_path_matches_the_frozen_digests(srt, gpu, name, count_traversal):
     scene, cam, W, H, spp, depth, _ = digest_workloads(srt)[name]
     out = srt.render_image(scene, cam, W, H, spp, depth, renderer=gpu, count_traversal=count_traversal)
     assert digest_of_render(out) == _strip(GOLDEN[name]), name
+
+
+@pytest.mark.gpu
+def test_headline_frame_checksum_is_frozen(srt, gpu):
+    """The framebuffer checksum bench.py prints for the headline workload (random-spheres scene, 1920x1080, 1024 spp, depth 16: 5.2 G rays,
+    0.36 s on the GPU) -- the sum of the quantised planes -- on the SAH builder's tree: 895685023 since the v16 tree of round 2, the same
+    through every kernel version since (and, as it happens, on the throughput-tuned tree of round 4 as well).  The whole frame was compared
+    with the CPU oracle block by block in rounds 2, 4 and 5 (profiles/r0*/full_frame_parity_cfg3*.txt); this asserts that nothing moved it."""
+    scene = srt.Scene.builtin(srt.SCENE_RANDOM_SPHERES, 0).build_bvh(srt.BVH_SAH, 1984)
+    W, H = 1920, 1080
+    gpu.upload_scene(scene); gpu.set_camera(scene.default_camera(W, H)); gpu.set_partition(0, 1)
+    gpu.init_device_params(W, H, 1024, 16, 1984)
+    gpu.set_count_traversal(False)
+    gpu.render_chunk(W, H)
+    gpu.scatter_tiles()
+    assert int(sum(int(p.astype("int64").sum()) for p in gpu.read_fb())) == 895685023

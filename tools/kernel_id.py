@@ -26,8 +26,16 @@ OBJ = os.path.join(ROOT, "cuda-spectral-ray-tracer_amd", "csrc", "_build", "srt_
 LIB = os.path.join(ROOT, "cuda-spectral-ray-tracer_amd", "libsrt_hip.so")
 
 
-RENDER = re.compile(r"^_ZN3srt13render_kernelILi0ELb([01])ELb([01])E\w*:")      # render_kernel<0, NARROW, ALL_CACHED>: the production builds
-RENDER_SYM = re.compile(r"^_ZN3srt13render_kernelILi0ELb([01])ELb([01])EEEv\w*$")
+# render_kernel<0, NARROW, ALL_CACHED[, PAIRED]>: the production builds (PAIRED is round 5's fourth template argument; listings / libraries of
+# earlier rounds have three)
+RENDER = re.compile(r"^_ZN3srt13render_kernelILi0ELb([01])ELb([01])E(?:Lb([01])E)?\w*:")
+RENDER_SYM = re.compile(r"^_ZN3srt13render_kernelILi0ELb([01])ELb([01])E(?:Lb([01])E)?EEv\w*$")
+
+
+def _key(m):
+    """(narrow, all_cached) for the general variant, (narrow, all_cached, 1) for the PAIRED one"""
+    k = (int(m.group(1)), int(m.group(2)))
+    return k + (1,) if m.group(3) == "1" else k
 BUNDLE_MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
 
 
@@ -97,17 +105,22 @@ def code_hashes(lib=LIB):
                 for name, code in _elf_function_bytes(data[pos + off:pos + off + size]).items():
                     m = RENDER_SYM.match(name)
                     if m:
-                        out[(int(m.group(1)), int(m.group(2)))] = hashlib.sha256(position_independent(code)).hexdigest()
+                        out[_key(m)] = hashlib.sha256(position_independent(code)).hexdigest()
         pos = data.find(BUNDLE_MAGIC, pos + 1)
     return out
 
 
-def code_hash(lib=LIB, narrow=1, all_cached=1):
-    """(hash, note) of render_kernel<0, narrow, all_cached> inside `lib`"""
+def variant_name(narrow, all_cached, paired=0):
+    return "render_kernel<0,%d,%d%s>" % (narrow, all_cached, ",paired" if paired else "")
+
+
+def code_hash(lib=LIB, narrow=1, all_cached=1, paired=0):
+    """(hash, note) of render_kernel<0, narrow, all_cached[, PAIRED]> inside `lib`"""
     hs = code_hashes(lib)
-    if (narrow, all_cached) not in hs:
-        return None, "render_kernel<0,%d,%d> not found in the gfx950 code object of %s" % (narrow, all_cached, lib)
-    return hs[(narrow, all_cached)], "sha256 of the machine code of render_kernel<0,%d,%d> in the gfx950 code object of %s" % (narrow, all_cached, os.path.relpath(lib, ROOT))
+    key = (narrow, all_cached, 1) if paired else (narrow, all_cached)
+    if key not in hs:
+        return None, "%s not found in the gfx950 code object of %s" % (variant_name(narrow, all_cached, paired), lib)
+    return hs[key], "sha256 of the machine code of %s in the gfx950 code object of %s" % (variant_name(narrow, all_cached, paired), os.path.relpath(lib, ROOT))
 
 
 def isa_hashes():
@@ -123,7 +136,7 @@ def isa_hashes():
             m = RENDER.match(line)
             if not m:
                 continue
-            h, key = hashlib.sha256(), (int(m.group(1)), int(m.group(2)))
+            h, key = hashlib.sha256(), _key(m)
         body = re.sub(r";.*$", "", line).rstrip()
         if body and not re.match(r"\s*\.(file|ident|loc)\b", body):
             h.update(body.encode() + b"\n")
@@ -133,7 +146,7 @@ def isa_hashes():
     return out
 
 
-def isa_hash(narrow=1, all_cached=1):
+def isa_hash(narrow=1, all_cached=1, paired=0):
     """(hash, note) of one production variant from the build's listing; (None, why) when the listing cannot speak for the library
     that is loaded: SRT_LIB_PATH names another library, or the in-tree library is older than the listing's object (a listing
     left over from another build)."""
@@ -147,14 +160,15 @@ def isa_hash(narrow=1, all_cached=1):
             return None, "the ISA listing's object is newer than libsrt_hip.so: the library was not linked from it"
     except OSError:
         pass
-    if (narrow, all_cached) not in hs:
-        return None, "render_kernel<0,%d,%d> not in the ISA listing" % (narrow, all_cached)
-    return hs[(narrow, all_cached)], "sha256 of the gfx950 ISA of render_kernel<0,%d,%d> (comments and .file/.ident/.loc lines removed)" % (narrow, all_cached)
+    key = (narrow, all_cached, 1) if paired else (narrow, all_cached)
+    if key not in hs:
+        return None, "%s not in the ISA listing" % variant_name(narrow, all_cached, paired)
+    return hs[key], "sha256 of the gfx950 ISA of %s (comments and .file/.ident/.loc lines removed)" % variant_name(narrow, all_cached, paired)
 
 
 if __name__ == "__main__":
     lib = sys.argv[1] if len(sys.argv) > 1 else LIB
     for k, v in sorted(code_hashes(lib).items()):
-        print("code    render_kernel<0,%d,%d> %s  (%s)" % (k[0], k[1], v, os.path.relpath(lib, ROOT)))
+        print("code    %s %s  (%s)" % (variant_name(*k), v, os.path.relpath(lib, ROOT)))
     for k, v in sorted(isa_hashes().items()):
-        print("listing render_kernel<0,%d,%d> %s" % (k[0], k[1], v))
+        print("listing %s %s" % (variant_name(*k), v))

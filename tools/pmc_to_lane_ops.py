@@ -18,6 +18,9 @@ argv = list(sys.argv)
 second = None
 if "--traffic" in argv:
     k = argv.index("--traffic"); second = argv[k + 1]; del argv[k:k + 2]
+key = None
+if "--key" in argv:      # entry name (default scene_<id>; e.g. scene_100_builders_tree for another tree of the same scene)
+    k = argv.index("--key"); key = argv[k + 1]; del argv[k:k + 2]
 sys.argv = argv
 d, tag = sys.argv[1], sys.argv[2]
 scene = int(sys.argv[3]) if len(sys.argv) > 3 else 100
@@ -74,6 +77,6 @@ entry = {
 out = sys.argv[4] if len(sys.argv) > 4 else os.path.join(ROOT, "profiles", "r05", "lane_ops_per_ray.json")
 os.makedirs(os.path.dirname(out), exist_ok=True)
 doc = json.load(open(out)) if os.path.exists(out) else {}
-doc["scene_%d" % scene] = entry
+doc[key or "scene_%d" % scene] = entry
 json.dump(doc, open(out, "w"), indent=1)
 print(json.dumps({k: v for k, v in entry.items() if k != "counters"}, indent=1))

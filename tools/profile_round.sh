@@ -8,12 +8,12 @@ TAG=${1:-vX}
 OUT="$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p "$OUT"
-[ "${2:-}" = "pmc-only" ] || timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python bench.py --no-cpu-baseline --no-other-configs --cfg5-spp 0 > "$OUT/bench.json" 2> "$OUT/bench.err" || { echo "trace run failed"; tail -5 "$OUT/bench.err"; exit 1; }
+[ "${2:-}" = "pmc-only" ] || timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python bench.py --no-cpu-baseline --no-other-configs --cfg5-spp 0 --no-builders-tree > "$OUT/bench.json" 2> "$OUT/bench.err" || { echo "trace run failed"; tail -5 "$OUT/bench.err"; exit 1; }
 [ "${2:-}" = "pmc-only" ] || cat "$OUT/bench.json"
 [ "${2:-}" = "pmc-only" ] || find "$OUT/trace" -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats.csv" \;
 [ "${2:-}" = "pmc-only" ] || cat "$OUT/kernel_stats.csv"
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/pmc_$C" -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-calibration --no-other-configs --cfg5-spp 0 > "$OUT/pmc_$C.json" 2> "$OUT/pmc_$C.err" || { echo "pmc $C failed"; exit 1; }
+  timeout -k 10 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/pmc_$C" -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-calibration --no-other-configs --cfg5-spp 0 --no-builders-tree > "$OUT/pmc_$C.json" 2> "$OUT/pmc_$C.err" || { echo "pmc $C failed"; exit 1; }
 done
 python - "$OUT" <<'PY'
 import csv, glob, sys, collections, json
