@@ -25,7 +25,7 @@ struct srt_ctx {
     int device = 0;
     std::string err;
     // scene images in HBM
-    float *d_nodes = nullptr, *d_fringe = nullptr, *d_tris = nullptr, *d_mat_sd = nullptr, *d_mat_par = nullptr, *d_shade = nullptr, *d_cmf = nullptr;
+    float *d_nodes = nullptr, *d_nodes_sw = nullptr, *d_fringe = nullptr, *d_tris = nullptr, *d_mat_sd = nullptr, *d_mat_par = nullptr, *d_shade = nullptr, *d_cmf = nullptr;
     int root_ref = 0, stack_depth = 1, n_inner = 0, n_records = 0;
     bool paired = false;               // the uploaded tree has no node with exactly one leaf child (srt_scene_is_paired)
     uint32_t fringe_stride = 96;       // bytes between FRINGE records in d_fringe
@@ -134,7 +134,7 @@ int upload(srt_ctx *ctx, T **dst, const std::vector<float> &src) {
 
 void fill_params(const srt_ctx *c, RenderParams &p) {
     memset(&p, 0, sizeof(p));
-    p.nodes = (const float4 *)c->d_nodes; p.fringe = (const float4 *)c->d_fringe; p.tris = (const float4 *)c->d_tris;
+    p.nodes = (const float4 *)c->d_nodes; p.nodes_sw = c->d_nodes_sw; p.fringe = (const float4 *)c->d_fringe; p.tris = (const float4 *)c->d_tris;
     p.mat_sd = (const float2 *)c->d_mat_sd; p.mat_par = (const float4 *)c->d_mat_par;
     p.shade = (const float4 *)c->d_shade; p.cmf = (const float4 *)c->d_cmf;
     p.root_ref = c->root_ref; p.stack_depth = c->stack_depth; p.n_materials = c->n_materials;
@@ -206,7 +206,7 @@ void srt_destroy(srt_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    void *bufs[] = {c->d_nodes, c->d_fringe, c->d_tris, c->d_mat_sd, c->d_mat_par, c->d_shade, c->d_cmf, c->d_rng, c->d_fb, c->d_tiles, c->d_counters, c->d_tile_cost, c->d_tile_order, c->d_rowmajor, c->d_wave_debug};
+    void *bufs[] = {c->d_nodes, c->d_nodes_sw, c->d_fringe, c->d_tris, c->d_mat_sd, c->d_mat_par, c->d_shade, c->d_cmf, c->d_rng, c->d_fb, c->d_tiles, c->d_counters, c->d_tile_cost, c->d_tile_order, c->d_rowmajor, c->d_wave_debug};
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -244,6 +244,9 @@ int srt_upload_scene(srt_ctx *c, const srt_scene *s) {
             if ((rc = upload(c, &c->d_fringe, padded)) != SRT_OK) return rc;
         }
         c->fringe_stride = stride;
+        // (the pre-swizzled copy of the INNER records: only trees whose INNER visits read memory need it)
+        if (c->d_nodes_sw) { (void)hipFree(c->d_nodes_sw); c->d_nodes_sw = nullptr; }
+        if (!plan.all_cached && (rc = upload(c, &c->d_nodes_sw, f.nodes_sw)) != SRT_OK) return rc;
     }
     if ((rc = upload(c, &c->d_tris, f.tris)) != SRT_OK) return rc;
     if ((rc = upload(c, &c->d_mat_sd, f.mat_sd)) != SRT_OK) return rc;
@@ -396,7 +399,9 @@ int srt_render_chunk(srt_ctx *c, uint32_t width, uint32_t height, uint32_t offx,
         // (inner records that come from L2 make an INNER visit ~2x as expensive, so shading and FRINGE visits weigh more:
         // plateau 280-400 / 560-1100 on cfg 5's scene, 60-85 / 280-340 on cfg 2 / 3 / 4, profiles/r02/knob_sweeps.txt)
         p.score_shade = c->score_shade ? c->score_shade : (all_cached ? 70u : kScoreShadeL2);
-        p.score_fringe = c->score_fringe ? c->score_fringe : (all_cached ? 280u : kScoreFringeL2);
+        // (the PAIRED variant's FRINGE visit is a fifth cheaper: plateau 340-480 on cfg 3, profiles/r05/experiments/weights_paired.txt)
+        const bool paired = render_paired_variant(c->paired, render_narrow_refs(c->n_records, c->knobs), all_cached);
+        p.score_fringe = c->score_fringe ? c->score_fringe : (all_cached ? (paired ? 400u : 280u) : kScoreFringeL2);
     }
     // ---- cost-ordered pixel queue --------------------------------------------------------------------------------
     // A pixel is one sequential RNG stream, so the launch cannot finish before its most expensive pixel does.  A short

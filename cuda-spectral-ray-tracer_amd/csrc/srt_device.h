@@ -329,6 +329,7 @@ typedef __attribute__((address_space(3))) const f2 lds_cf2;
 typedef __attribute__((address_space(3))) const char lds_cchar;
 struct NodeSrc {
     buf_rsrc global_nodes;               // INNER records, 64 B each
+    buf_rsrc global_nodes_sw;            // the same records pre-swizzled, 80 B each (flatten_scene): read by inner_burst4_mixed_asm
     buf_rsrc global_fringe;              // FRINGE records, 96 B each (fringe_stride apart), indexed by record - n_inner
     uint32_t fringe_stride;
     int n_inner;
@@ -662,6 +663,115 @@ __device__ __forceinline__ uint32_t inner_phase_asm(Trav &tv, const NodeSrc &ns,
           "v115", "v116", "v117", "v118", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "vcc",
           "scc", "memory");
     return kind;
+}
+
+// A burst of up to four INNER visits for a tree that is only PARTLY LDS resident (32-bit references; production build of
+// render_kernel<0, false, false, .>), hand-scheduled like inner_burst8_asm.  The compiler's form of this visit -- `if (cached) LDS else
+// memory` around one shared arithmetic block -- is ~100 instructions: three register copies per visit for the loop-carried state, the
+// memory path's twelve near / far selects, a full `s_waitcnt vmcnt(0)` BEFORE the first LDS read of the other lanes, an exec juggle per
+// region.  Here (~72):
+//   * the lanes beyond the LDS prefix load a PRE-SWIZZLED copy of their record (80 B: per axis lo_L lo_R hi_L hi_R lo_L lo_R; a
+//     16-byte load at +0 or +8 IS (near pair, far pair)) -- the selection of aabb.cu:21-25 by address, like the LDS lanes' -- so both
+//     kinds of lanes fill the same twelve registers and the arithmetic block is shared without a single select;
+//   * the memory loads are issued first, the LDS reads of the other lanes go out while they fly, one wait pair before the arithmetic;
+//   * EXEC is saved once per burst and narrowed by v_cmpx like in inner_burst8_asm; the two sub-masks of a visit cost one s_and_saveexec
+//     and one s_andn2.
+// Arithmetic: instruction for instruction trav_step_inner's (same operands, same order).  Registers v100-v118, s80-s91 are scratch.
+#define SRT_INNER_VISIT_MIXED_ASM                                                                                        \
+    "ds_write_b32 %[sp], %[top] offset:256\n\t"                                                                          \
+    "ds_read_b32 v116, %[sp]\n\t"                                   /* below */                                           \
+    "v_cmp_le_u32 vcc, %[ncached], %[node]\n\t"                     /* lanes beyond the LDS prefix */                     \
+    "s_and_saveexec_b64 s[90:91], vcc\n\t"                                                                               \
+    "s_cbranch_execz 1f\n\t"                                                                                             \
+    "v_mul_u32_u24 v117, 0x50, %[node]\n\t"                         /* 80-byte records */                                 \
+    "v_add_u32 v114, v117, %[g0]\n\t"                                                                                    \
+    "v_add_u32 v115, v117, %[g1]\n\t"                                                                                    \
+    "v_add_u32 v118, v117, %[g2]\n\t"                                                                                    \
+    "buffer_load_dwordx4 v[100:103], v114, %[rsrc], 0 offen\n\t"                                                         \
+    "buffer_load_dwordx4 v[104:107], v115, %[rsrc], 0 offen offset:24\n\t"                                               \
+    "buffer_load_dwordx4 v[108:111], v118, %[rsrc], 0 offen offset:48\n\t"                                               \
+    "buffer_load_dwordx2 v[112:113], v117, %[rsrc], 0 offen offset:72\n\t"                                               \
+    "1:\n\t"                                                                                                             \
+    "s_andn2_b64 exec, s[90:91], vcc\n\t"                           /* lanes inside the prefix */                         \
+    "s_cbranch_execz 2f\n\t"                                                                                             \
+    "v_lshlrev_b32 v117, 4, %[node]\n\t"                                                                                 \
+    "v_add_u32 v114, v117, %[nf0]\n\t"                                                                                   \
+    "v_add_u32 v115, v117, %[nf1]\n\t"                                                                                   \
+    "v_add_u32 v118, v117, %[nf2]\n\t"                                                                                   \
+    "ds_read_b64 v[100:101], v114\n\t"                                                                                   \
+    "v_xor_b32 v114, 8, v114\n\t"                                                                                        \
+    "ds_read_b64 v[102:103], v114\n\t"                                                                                   \
+    "ds_read_b64 v[104:105], v115\n\t"                                                                                   \
+    "v_xor_b32 v115, 8, v115\n\t"                                                                                        \
+    "ds_read_b64 v[106:107], v115\n\t"                                                                                   \
+    "ds_read_b64 v[108:109], v118\n\t"                                                                                   \
+    "v_xor_b32 v118, 8, v118\n\t"                                                                                        \
+    "ds_read_b64 v[110:111], v118\n\t"                                                                                   \
+    "v_lshl_add_u32 v117, %[node], 2, %[refs0]\n\t"                                                                      \
+    "ds_read_b32 v112, v117\n\t"                                    /* lref */                                            \
+    "v_lshl_add_u32 v117, %[node], 2, %[refs1]\n\t"                                                                      \
+    "ds_read_b32 v113, v117\n\t"                                    /* rref */                                            \
+    "2:\n\t"                                                                                                             \
+    "s_mov_b64 exec, s[90:91]\n\t"                                                                                       \
+    "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"                                                                                  \
+    "v_pk_add_f32 v[100:101], v[100:101], %[p0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t" /* near x - o.x */        \
+    "v_pk_add_f32 v[102:103], v[102:103], %[p0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t" /* far  x - o.x */        \
+    "v_pk_mul_f32 v[100:101], %[p1], v[100:101] op_sel:[1,0]\n\t"                              /* * inv.x */             \
+    "v_pk_mul_f32 v[102:103], %[p1], v[102:103] op_sel:[1,0]\n\t"                                                        \
+    "v_pk_add_f32 v[106:107], v[106:107], %[p0] op_sel:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"    /* far  y - o.y */        \
+    "v_pk_add_f32 v[104:105], v[104:105], %[p0] op_sel:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"    /* near y - o.y */        \
+    "v_pk_mul_f32 v[106:107], %[p2], v[106:107] op_sel_hi:[0,1]\n\t"                           /* * inv.y */             \
+    "v_pk_mul_f32 v[104:105], %[p2], v[104:105] op_sel_hi:[0,1]\n\t"                                                     \
+    "v_pk_add_f32 v[108:109], v[108:109], %[p1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t" /* near z - o.z */        \
+    "v_pk_add_f32 v[110:111], v[110:111], %[p1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t" /* far  z - o.z */        \
+    "v_pk_mul_f32 v[108:109], %[p2], v[108:109] op_sel:[1,0]\n\t"                              /* * inv.z */             \
+    "v_pk_mul_f32 v[110:111], %[p2], v[110:111] op_sel:[1,0]\n\t"                                                        \
+    "v_max_f32 v100, 0, v100\n\t"                                                                                        \
+    "v_min_f32 v102, v102, v106\n\t"                                                                                     \
+    "v_max3_f32 v100, v100, v104, v108\n\t"                        /* e_l */                                             \
+    "v_max_f32 v101, 0, v101\n\t"                                                                                        \
+    "v_min_f32 v103, v103, v107\n\t"                                                                                     \
+    "v_min3_f32 v102, %[c], v102, v110\n\t"                        /* min(c, m_l) */                                     \
+    "v_max3_f32 v101, v101, v105, v109\n\t"                        /* e_r */                                             \
+    "v_cmp_nle_f32 vcc, v102, v100\n\t"                            /* trav_l */                                          \
+    "v_min3_f32 v100, %[c], v103, v111\n\t"                        /* min(c, m_r) */                                     \
+    "v_cmp_nle_f32_e64 s[82:83], v100, v101\n\t"                   /* trav_r */                                          \
+    "s_or_b64 s[84:85], vcc, s[82:83]\n\t"                         /* any */                                             \
+    "v_cndmask_b32_e64 v118, %[top], v113, s[82:83]\n\t"                                                                 \
+    "v_cndmask_b32_e32 %[node], v118, v112, vcc\n\t"                                                                     \
+    "s_and_b64 vcc, vcc, s[82:83]\n\t"                             /* both */                                            \
+    "v_cndmask_b32_e64 v118, %[ms], 0, s[84:85]\n\t"                                                                     \
+    "v_cndmask_b32_e64 %[top], v116, %[top], s[84:85]\n\t"                                                               \
+    "v_cndmask_b32_e32 v118, v118, %[ps], vcc\n\t"                                                                       \
+    "v_cndmask_b32_e32 %[top], %[top], v113, vcc\n\t"                                                                    \
+    "v_add_u32 %[sp], v118, %[sp]\n\t"
+#define SRT_INNER_NEXT_MIXED_ASM                                                                                         \
+    "v_cmpx_gt_u32 vcc, %[ninner], %[node]\n\t"                                                                          \
+    "s_bcnt1_i32_b64 s86, exec\n\t"                                                                                      \
+    "s_cmp_lt_u32 s86, %[stay]\n\t"                                                                                      \
+    "s_cbranch_scc1 .Lsrt_mixed_end%=\n\t"
+__device__ __forceinline__ void inner_burst4_mixed_asm(Trav &tv, const NodeSrc &ns, V3 o, V3 inv, uint32_t n_inner, uint32_t stay) {
+    const f2 p0 = mk2(o.x, o.y), p1 = mk2(o.z, inv.x), p2 = mk2(inv.y, inv.z);
+    const int minus_stride = -kStackStride<false>, plus_stride = kStackStride<false>;
+    const uint32_t refs0 = (uint32_t)(uintptr_t)ns.lds_r0, refs1 = (uint32_t)(uintptr_t)ns.lds_r1;
+    // byte offset of the (near, far) image inside an axis entry of the pre-swizzled record: 0 for a positive direction, 8 for a negative
+    // one -- bit 3 of the ray's LDS plane addresses says which (the planes are 16-byte aligned)
+    const uint32_t g0 = tv.nf[0] & 8u, g1 = tv.nf[1] & 8u, g2 = tv.nf[2] & 8u;
+    asm volatile(
+        "s_mov_b64 s[80:81], exec\n\t"
+        "v_cmpx_gt_u32 vcc, %[ninner], %[node]\n\t"
+        SRT_INNER_VISIT_MIXED_ASM SRT_INNER_NEXT_MIXED_ASM
+        SRT_INNER_VISIT_MIXED_ASM SRT_INNER_NEXT_MIXED_ASM
+        SRT_INNER_VISIT_MIXED_ASM SRT_INNER_NEXT_MIXED_ASM
+        SRT_INNER_VISIT_MIXED_ASM
+        ".Lsrt_mixed_end%=:\n\t"
+        "s_mov_b64 exec, s[80:81]\n\t"
+        : [node] "+v"(tv.node), [top] "+v"(tv.top), [sp] "+v"(tv.sp)
+        : [nf0] "v"(tv.nf[0]), [nf1] "v"(tv.nf[1]), [nf2] "v"(tv.nf[2]), [g0] "v"(g0), [g1] "v"(g1), [g2] "v"(g2), [p0] "v"(p0), [p1] "v"(p1), [p2] "v"(p2),
+          [c] "v"(tv.c), [ms] "v"(minus_stride), [ps] "v"(plus_stride), [ninner] "s"(n_inner), [ncached] "s"((uint32_t)ns.n_cached), [refs0] "s"(refs0),
+          [refs1] "s"(refs1), [stay] "s"(stay), [rsrc] "s"(ns.global_nodes_sw)
+        : "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114",
+          "v115", "v116", "v117", "v118", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s90", "s91", "vcc", "scc", "memory");
 }
 
 // Visit of a FRINGE record (at least one leaf child), in two halves so that a caller can put independent work (a burst of

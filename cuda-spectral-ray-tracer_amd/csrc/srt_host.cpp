@@ -627,6 +627,18 @@ int flatten_scene(const srt_scene &s, FlatScene &out) {
             }
         }
     }
+    // The same INNER records once more, 80 B each, for the visit that reads them from MEMORY (trees that do not fit LDS, production
+    // build: inner_burst4_mixed_asm): per axis (lo_L, lo_R, hi_L, hi_R, lo_L, lo_R) -- a 16-byte load at +0 delivers (near pair, far
+    // pair) for a ray that travels in the positive direction, the same load at +8 for a negative one, exactly the register image the
+    // LDS-served lanes of the same visit get from their two 8-byte reads: the selection of aabb.cu:21-25 by ADDRESS here too, no
+    // v_cndmask.  Then lref, rref.
+    out.nodes_sw.assign(20 * std::max<size_t>(n_in, 1), 0.f);
+    for (size_t r = 0; r < n_in; r++) {
+        const float *o = &out.nodes[16 * r];
+        float *w = &out.nodes_sw[20 * r];
+        for (int a = 0; a < 3; a++) { for (int k = 0; k < 4; k++) w[6 * a + k] = o[4 * a + k]; w[6 * a + 4] = o[4 * a + 0]; w[6 * a + 5] = o[4 * a + 1]; }
+        w[18] = o[12]; w[19] = o[13];
+    }
     out.root_ref = child_ref(s.root);
     out.n_records = (int)pre.size();
     // Entries the traversal stack can hold at once: a push happens only at an INNER record (both children internal, bvh.cu:154-160:

@@ -79,6 +79,7 @@ bool tree_is_paired(const srt_scene &s);      // every internal node has two lea
 
 struct FlatScene {
     std::vector<float> nodes;    // 16 floats per INNER record (both children internal)
+    std::vector<float> nodes_sw; // 20 floats per INNER record, pre-swizzled for the L2-served assembly visit (see flatten_scene)
     std::vector<float> fringe;   // 24 floats per FRINGE record (a leaf child; triangle data inline, (left, right) pairs), record index - n_inner
     std::vector<float> tris;     // 12 floats per triangle
     std::vector<float> mat_sd;   // 192 floats per material, then 192 for the background (table index n_materials)

@@ -22,6 +22,7 @@ constexpr int kCounters = 32;       // rays, node_visits, tri_tests, box_tests, 
 struct RenderParams {
     // scene (HBM layout: DESIGN.md)
     const float4 *nodes;       // 4 float4 per INNER record (records [0, n_inner))
+    const float *nodes_sw;     // 20 floats per INNER record, pre-swizzled (srt_host.cpp, flatten_scene); null when the tree is LDS resident
     const float4 *fringe;      // 6 float4 per FRINGE record (records [n_inner, n_records)), triangle data inline
     const float4 *tris;        // 3 float4 per triangle
     const float2 *mat_sd;      // per material 96 pairs (94 used): (sd[k], sd[k+1]); table n_materials = the background

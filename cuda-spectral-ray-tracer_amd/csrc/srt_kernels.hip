@@ -34,6 +34,9 @@ namespace srt {
 #ifndef SRT_INNER_BURST_L2
 #define SRT_INNER_BURST_L2 4
 #endif
+#ifndef SRT_ASM_BURST_L2
+#define SRT_ASM_BURST_L2 1   /* 32-bit references, inner tree partly in L2 (cfg 5's mesh): INNER bursts in assembly (inner_burst4_mixed_asm) */
+#endif
 #ifndef SRT_BURST_DROP_L2
 #define SRT_BURST_DROP_L2 2
 #endif
@@ -184,6 +187,7 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
     // (a tree that fits LDS always has packed 96-byte FRINGE records -- srt_upload_scene -- so that variant keeps the literal)
     ns.fringe_stride = ALL_CACHED ? 96u : P.fringe_stride;
     ns.global_fringe = make_rsrc(P.fringe, (uint32_t)(P.n_records - P.n_inner) * ns.fringe_stride);
+    ns.global_nodes_sw = make_rsrc(P.nodes_sw, P.nodes_sw ? (uint32_t)P.n_inner * 80u : 0u);
     ns.n_inner = P.n_inner;
     ns.lds_q0 = (lds_cf4 *)s_q0; ns.lds_q1 = (lds_cf4 *)s_q1; ns.lds_q2 = (lds_cf4 *)s_q2;
     ns.lds_r0 = (lds_cu32 *)s_r0; ns.lds_r1 = (lds_cu32 *)s_r1;
@@ -640,6 +644,8 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
                 const uint32_t stay = (n_trav - n_fringe + burst_drop - 1u) / burst_drop;
                 if (!ITERS && NARROW && ALL_CACHED && kInnerBurst == 8 && SRT_ASM_BURST == 1) {
                     inner_burst8_asm(tv, ns, ro, inv, n_inner_u, stay);      // the same eight visits, hand-scheduled (srt_device.h)
+                } else if (!ITERS && !NARROW && !ALL_CACHED && kInnerBurstL2 == 4 && SRT_ASM_BURST_L2 && P.nodes_sw != nullptr) {
+                    inner_burst4_mixed_asm(tv, ns, ro, inv, n_inner_u, stay);      // LDS prefix + memory, hand-scheduled (srt_device.h)
                 } else
 #pragma unroll
                 for (int burst = 0; burst < burst_len; burst++) {
@@ -888,6 +894,7 @@ __global__ __launch_bounds__(64) void trace_rays_kernel(const RenderParams P, co
     ns.global_nodes = make_rsrc(P.nodes, (uint32_t)P.n_inner * 64u);
     ns.global_fringe = make_rsrc(P.fringe, (uint32_t)(P.n_records - P.n_inner) * P.fringe_stride);
     ns.fringe_stride = P.fringe_stride;
+    ns.global_nodes_sw = make_rsrc(nullptr, 0u);
     ns.n_inner = P.n_inner;
     ns.lds_q0 = ns.lds_q1 = ns.lds_q2 = nullptr; ns.lds_r0 = ns.lds_r1 = nullptr; ns.n_cached = 0;
     while (__ballot(tv.node >= 0) != 0ull) {

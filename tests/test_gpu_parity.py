@@ -918,6 +918,30 @@ def _assert_render_matches(out, ref, what, count_traversal, n_tris):
 
 
 @pytest.mark.parametrize("count_traversal", VARIANTS)
+@pytest.mark.parametrize("cap", [0, 3, 40])
+@pytest.mark.parametrize("sid,mode,W,H,spp,depth", [SCENES[0], SCENES[2], SCENES[3], SCENES[4], SCENES[8], SCENES[9], SCENES[11]])
+def test_wide_references_partly_cached_forced_on_small_scenes(srt, gpu, orc, sid, mode, W, H, spp, depth, cap, count_traversal):
+    """render_kernel<MODE, NARROW = false, ALL_CACHED = false[, PAIRED]> -- the shape cfg 5's mesh launches -- forced on the small scenes with
+    both test knobs (32-bit references, LDS cache capped at 0 / 3 / 40 records): the production build's INNER bursts are the hand-scheduled
+    mixed-source block of round 5 (inner_burst4_mixed_asm: lanes inside the LDS prefix and lanes that read the pre-swizzled 80-byte records
+    from memory in one visit; cap 0 = every lane from memory), the instrumented build's are the C++ visit: both == the oracle bit for bit."""
+    gpu.set_test_knobs(wide_refs=True, lds_cache_max=cap)
+    scene = srt.Scene.builtin(sid, 0).build_bvh(mode, 1984)
+    try:
+        cam = scene.default_camera(W, H)
+        out = srt.render_image(scene, cam, W, H, spp, depth, renderer=gpu, count_traversal=count_traversal)
+        plan = gpu.launch_plan()
+        assert not plan["narrow_refs"] and plan["n_cached"] <= cap
+        if scene.n_nodes > 2 * cap + 3:
+            assert not plan["all_cached"]
+        ref = oracle_scene_for(orc, scene, mode).render(cam, W, H, spp, depth)
+        _assert_render_matches(out, ref, "scene %d, wide references, cap %d" % (sid, cap), count_traversal, scene.n_tris)
+    finally:
+        gpu.set_test_knobs()
+        gpu.upload_scene(scene)
+
+
+@pytest.mark.parametrize("count_traversal", VARIANTS)
 @pytest.mark.parametrize("n,expect_paired", [(600, True), (601, False), (2, True), (3, False), (40000, True), (40001, False)])
 def test_paired_trees_launch_the_paired_variant_and_stay_exact(srt, gpu, orc, n, expect_paired, count_traversal):
     """Round 5: the SAH builder cuts every even span into two even halves, so a scene with an even triangle count gets a PAIRED tree (every

@@ -45,7 +45,7 @@ def test_hip_path_matches_the_frozen_digests(srt, gpu, name, count_traversal):
 @pytest.mark.gpu
 def test_headline_frame_checksum_is_frozen(srt, gpu):
     """The framebuffer checksum bench.py prints for the headline workload (random-spheres scene, 1920x1080, 1024 spp, depth 16: 5.2 G rays,
-    0.36 s on the GPU) -- the sum of the quantised planes -- on the SAH builder's tree: 895685023 since the v16 tree of round 2, the same
+    0.36 s on the GPU) -- the sum of the quantised planes -- on the SAH builder's tree: 895685025 on the paired (even-split) tree of round 5 -- 895685023 on the builder's tree of rounds 2-4, the same
     through every kernel version since (and, as it happens, on the throughput-tuned tree of round 4 as well).  The whole frame was compared
     with the CPU oracle block by block in rounds 2, 4 and 5 (profiles/r0*/full_frame_parity_cfg3*.txt); this asserts that nothing moved it."""
     scene = srt.Scene.builtin(srt.SCENE_RANDOM_SPHERES, 0).build_bvh(srt.BVH_SAH, 1984)
@@ -55,4 +55,4 @@ def test_headline_frame_checksum_is_frozen(srt, gpu):
     gpu.set_count_traversal(False)
     gpu.render_chunk(W, H)
     gpu.scatter_tiles()
-    assert int(sum(int(p.astype("int64").sum()) for p in gpu.read_fb())) == 895685023
+    assert int(sum(int(p.astype("int64").sum()) for p in gpu.read_fb())) == 895685025
