@@ -38,6 +38,16 @@ D)
   timeout -k 10 300 python tools/diag.py --scene 101 --width 3840 --height 2160 --spp 128 --reps 1 > $O/diag_cfg5_128spp.json 2>&1
   timeout -k 10 300 python tools/diag.py --spp 64 > $O/diag_cfg3_64spp.json 2>&1
   timeout -k 10 500 python tools/world_emulation.py --worlds 1,2,4,8 --reps 3 2>&1 | grep -v amdgpu.ids > $O/world_emulation_cfg3.txt; grep "^world" $O/world_emulation_cfg3.txt
+  timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --rehearse-gloo --spp 64 --steps 2 --warmup 1 --cfg5-spp 16 --cfg5-size 640x360 > $O/bench_torchrun2_gloo_rehearsal.json 2> $O/bench_torchrun2_gloo_rehearsal.err; echo "torchrun rehearsal rc=$?"
+  ;;
+E)
+  # cfg 5 as specified on one rank of eight (all eight, one after the other) and on one GPU: the strong-scaling emulation of the largest configuration
+  timeout -k 10 1100 python tools/world_emulation.py --scene 101 --width 3840 --height 2160 --spp 4096 --worlds 1,8 --reps 1 2>&1 | grep -v amdgpu.ids > $O/world_emulation_cfg5_4096spp.txt; grep "^world" $O/world_emulation_cfg5_4096spp.txt
+  ;;
+F)
+  # whole frame of cfg 5's scene (3840x2160 x 8 spp: 18 768 blocks) and of cfg 2 against the CPU oracle
+  SRT_LONG=1 SRT_LONG_CFG=5 SRT_LONG_SPP=8 SRT_LONG_THREADS=16 timeout -k 10 560 python -m pytest "tests/test_gpu_parity.py::test_full_frame_full_spp_bit_exact" -m gpu -x -q -s > $O/full_frame_cfg5_8spp.txt 2>&1; echo "cfg5 rc=$?"; tail -3 $O/full_frame_cfg5_8spp.txt
+  SRT_LONG=1 SRT_LONG_CFG=2 SRT_LONG_THREADS=16 timeout -k 10 400 python -m pytest "tests/test_gpu_parity.py::test_full_frame_full_spp_bit_exact" -m gpu -x -q -s > $O/full_frame_cfg2.txt 2>&1; echo "cfg2 rc=$?"; tail -3 $O/full_frame_cfg2.txt
   ;;
 esac
 rm -rf $O/pmc_*/pass*/
