@@ -361,15 +361,13 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
 #pragma unroll
                     for (int k = 0; k < kWavelengths; k++) {
                         const float4 r0 = s_cmf[off[k]], r1 = s_cmf[off[k] + 1];
-                        const float w = wgt[k], power = pw[k];
-                        const float tx_ = ((1.0f - w) * r0.x + w * r1.x) * power * delta_lambda;
-                        const float ty_ = ((1.0f - w) * r0.y + w * r1.y) * power * delta_lambda;
-                        const float tz_ = ((1.0f - w) * r0.z + w * r1.z) * power * delta_lambda;
-                        // the reference sums the first `valid` terms; the others are replaced by +0, which leaves a sum unchanged
-                        const bool live = (uint32_t)k < valid;
-                        xyz_x += live ? tx_ : 0.0f;
-                        xyz_y += live ? ty_ : 0.0f;
-                        xyz_z += live ? tz_ : 0.0f;
+                        // the reference sums the first `valid` terms; the others contribute +0, which leaves a sum unchanged: their POWER is
+                        // replaced by +0 (one select per wavelength instead of three per term) -- the interpolated colour-matching value is a
+                        // convex combination of non-negative table entries, so (value * +0) * delta = +0 exactly
+                        const float w = wgt[k], power = (uint32_t)k < valid ? pw[k] : 0.0f;
+                        xyz_x += ((1.0f - w) * r0.x + w * r1.x) * power * delta_lambda;
+                        xyz_y += ((1.0f - w) * r0.y + w * r1.y) * power * delta_lambda;
+                        xyz_z += ((1.0f - w) * r0.z + w * r1.z) * power * delta_lambda;
                     }
                 }
                 if (was_hit) {

@@ -871,6 +871,20 @@ def test_profiled_child_order_bit_exact(srt, gpu, orc, count_traversal, optimise
     assert gpu.order_children_by_profile(scene, W, H, spp, depth, min_samples=4) == 0
 
 
+def test_profiled_child_order_fails_loudly_without_samples(srt, gpu):
+    """a collecting probe launch that recorded nothing -- here a camera that looks away from the scene, so no query finds a triangle -- must
+    not read as "the builder's order was already the cheapest" (0 swaps): srt_order_children_by_profile returns SRT_ERR_INVALID with a message.  (The
+    profile header now sits at a fixed place in front of the per-wave debug words, so a launch cannot miss it either.)"""
+    scene = srt.Scene.builtin(srt.SCENE_RANDOM_SPHERES, 0).build_bvh(srt.BVH_SAH, 1984)
+    gpu.upload_scene(scene)
+    away = srt.camera_init(64, 48, 20.0, (13.0, 200.0, 3.0), (13.0, 400.0, 3.0), vup=(0, 0, 1))      # above the scene, looking up
+    gpu.set_camera(away)
+    with pytest.raises(srt.SrtError) as e:
+        gpu.order_children_by_profile(scene, 64, 48, 2, 4, 1)
+    assert e.value.code == -1 and "no samples" in str(e.value)
+    gpu.upload_scene(scene)
+
+
 def test_profiled_child_order_never_makes_the_probe_frame_worse(srt, gpu, orc):
     """The call checks its own result on the probe frame and undoes the swaps when the work counters did not fall: whatever it
     returns, the frame's node records + 2 x triangle tests are not above the builder's order's; 0 swaps = the tree is untouched."""
