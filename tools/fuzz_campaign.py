@@ -2,7 +2,10 @@
 """A longer run of the GPU suite's random-scene fuzz (tests/test_gpu_parity.py::test_random_scenes_fuzz: triangle soups with shared
 vertices / lattice coincidences / axis-aligned triangles, random materials incl. dielectric with quirk Q1 and emissive, both BVH
 builders, lens on / off, depth 1..16): GPU (both kernel builds) == oracle bit for bit, work counters included.  The oracle is the
-checker here, as in the tests.  usage: tools/fuzz_campaign.py [first seed] [count]"""
+checker here, as in the tests.  usage: tools/fuzz_campaign.py [first seed] [count]
+FUZZ_WIDE=1 / FUZZ_CACHE_MAX=n send every scene through the kernel variants it would not launch by itself (srt_set_test_knobs: 32-bit
+references, LDS cache capped at n records -- together the shape of cfg 5's mesh, whose production build runs the hand-scheduled mixed-source
+INNER bursts); FUZZ_TUNE=1 tunes every tree first.  About half of the SAH-built scenes have an even triangle count: paired trees, PAIRED variants."""
 import importlib, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -15,6 +18,8 @@ import test_gpu_parity as T
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 gpu = srt.Renderer(0); gpu.set_gather_planes(9)
+gpu.set_test_knobs(wide_refs=os.environ.get("FUZZ_WIDE") == "1", lds_cache_max=int(os.environ.get("FUZZ_CACHE_MAX", "-1")))
+n_paired = 0
 bad = 0
 swapped = 0
 for seed in range(first, first + count):
@@ -54,6 +59,7 @@ for seed in range(first, first + count):
         swapped += gpu.order_children_by_profile(scene, W, H, max(spp, 2), depth, int(rng.integers(1, 4)))
         mode = 1
     ref = oracle_scene_for(orc, scene, mode).render(cam, W, H, spp, depth)
+    n_paired += int(scene.is_paired)
     for counted in (True, False):
         out = srt.render_image(scene, cam, W, H, spp, depth, renderer=gpu, count_traversal=counted)
         ok = all(np.array_equal(bits(a), bits(b)) for a, b in zip(out["xyz"], ref["xyz"])) and all(np.array_equal(a, b) for a, b in zip(out["fb"], ref["fb"]))
@@ -66,5 +72,6 @@ for seed in range(first, first + count):
             print("MISMATCH seed %d counted=%s (%d tris, %d mats, mode %d, %dx%d %d spp depth %d)" % (seed, counted, n, n_mats, mode, W, H, spp, depth), flush=True)
     if (seed - first) % 25 == 24:
         print("seed %d done, %d mismatches so far" % (seed, bad), flush=True)
+print("knobs %s, %d of the %d trees paired" % (gpu.test_knobs(), n_paired, count))
 print("fuzz campaign: seeds %d..%d, both kernel builds, %d mismatches%s" % (first, first + count - 1, bad, (" (trees tuned: %d nodes swapped by the profiled order in all)" % swapped) if os.environ.get("FUZZ_TUNE") == "1" else ""))
 sys.exit(1 if bad else 0)
