@@ -20,6 +20,15 @@
 //  16 / 17 / 18  4 x buffer_load_dword / dwordx2 / dwordx3 at the same four offsets of the record, all 64 lanes -- does the cost of a
 //                vector-memory instruction in the CU's memory front end scale with its width?          19 / 20 / 21 the same, 16 lanes
 //  22 three dwordx4 + one dword (a 52-byte record), 16 lanes
+//  23-35 (round 5) what makes a vector instruction expensive -- its ENCODING (8 bytes: VOP3, a 32-bit literal, SDWA) or its operands?
+//  23 v_add_f32_e64 (two sources, VOP3 encoding)        24 v_add_f32 with a 32-bit literal (VOP2 + literal = 8 bytes)
+//  25 v_fmac_f32 (VOP2: 4 bytes, three register reads)   26 v_mov_b32                 27 v_cndmask_b32_e64 (mask in an SGPR pair)
+//  28 v_cndmask_b32_e32 (mask in VCC)                    29 v_mul_f32 with an SGPR source (4 bytes)   30 v_xor_b32
+//  31 v_pk_add_f32                                       32 v_rcp_f32                 33 v_cvt_f32_u32
+//  34 v_add_f32 SDWA (8 bytes, two sources)              35 v_fmamk_f32 (VOP2 + literal, three reads)
+//  36 v_cmp_lt_f32 -> VCC     37 v_cmp_lt_f32_e64 -> SGPR pair     38 s_mov vcc + 8 x v_cndmask_b32_e32     39 v_cndmask_b32_e64 with VCC     40 v_add_u32 with an SGPR source
+//  41-46 VOP2 selects (implicit VCC) in context: alternating with v_add; v_cmp + two consumers; v_cmp, three adds, consumer; s_and vcc + two VOP2
+//        consumers + six adds (the tail of the INNER visit); the same with VOP3-encoded selects; one stale-VCC select in eight
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -27,7 +36,7 @@
 
 namespace srt {
 
-constexpr int kCalibKinds = 23;
+constexpr int kCalibKinds = 47;
 
 #define REP4(x) x x x x
 
@@ -50,6 +59,8 @@ __global__ __launch_bounds__(1024) void calib_kernel(uint32_t iters, float *sink
     uint32_t lin_addr = (tid & 63u) * 8u;                               // conflict-free ds_read_b64
     uint32_t rnd_addr = ((tid * 2654435761u) >> 20) * 16u;              // 4096 records of 16 B, hashed per lane
     unsigned long long saved_exec = 0;
+    float sk = 1.0000001f; unsigned long long smask = 0x5555aaaa3333ccccull;
+    asm volatile("" : "+s"(sk), "+s"(smask));
     if (KIND == 10) asm volatile("s_mov_b64 %0, exec\n s_mov_b64 exec, 0x3ffffff" : "=s"(saved_exec));
     // kinds 11-15: random 64-byte records through a buffer descriptor, like the INNER visit of a tree that does not fit LDS
     typedef unsigned int u4v __attribute__((ext_vector_type(4)));
@@ -156,6 +167,52 @@ __global__ __launch_bounds__(1024) void calib_kernel(uint32_t iters, float *sink
                              "s_waitcnt vmcnt(4)\n"
                              : "=&v"(g0), "=&v"(g1), "=&v"(g2), "=&v"(h3) : "v"(off), "s"(rsrc) : "memory");
             }
+        } else if (KIND >= 23 && KIND <= 46) {
+#define SRT_CAL8(INS) REP4(asm volatile(INS(0) INS(1) INS(2) INS(3) INS(4) INS(5) INS(6) INS(7) \
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(k), "s"(sk), "s"(smask) : "vcc");)
+#define I23(n) "v_add_f32_e64 %" #n ", %" #n ", %8\n"
+#define I24(n) "v_add_f32 %" #n ", 0x3f800001, %" #n "\n"
+#define I25(n) "v_fmac_f32 %" #n ", %8, %8\n"
+#define I26(n) "v_mov_b32 %" #n ", %8\n"
+#define I27(n) "v_cndmask_b32_e64 %" #n ", %" #n ", %8, %10\n"
+#define I28(n) "v_cndmask_b32_e32 %" #n ", %" #n ", %8, vcc\n"
+#define I29(n) "v_mul_f32 %" #n ", %9, %" #n "\n"
+#define I30(n) "v_xor_b32 %" #n ", %" #n ", %8\n"
+#define I32(n) "v_rcp_f32 %" #n ", %" #n "\n"
+#define I33(n) "v_cvt_f32_u32 %" #n ", %" #n "\n"
+#define I34(n) "v_add_f32_sdwa %" #n ", %" #n ", %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n"
+#define I35(n) "v_fmamk_f32 %" #n ", %" #n ", 0x3f800001, %8\n"
+#define I36(n) "v_cmp_lt_f32 vcc, %" #n ", %8\n"
+#define I37(n) "v_cmp_lt_f32_e64 s[90:91], %" #n ", %8\n"
+#define I39(n) "v_cndmask_b32_e64 %" #n ", %" #n ", %8, vcc\n"
+#define I40(n) "v_add_u32 %" #n ", %9, %" #n "\n"
+            if (KIND == 23) { SRT_CAL8(I23) } else if (KIND == 24) { SRT_CAL8(I24) } else if (KIND == 25) { SRT_CAL8(I25) }
+            else if (KIND == 26) { SRT_CAL8(I26) } else if (KIND == 27) { SRT_CAL8(I27) } else if (KIND == 28) { SRT_CAL8(I28) }
+            else if (KIND == 29) { SRT_CAL8(I29) } else if (KIND == 30) { SRT_CAL8(I30) } else if (KIND == 32) { SRT_CAL8(I32) }
+            else if (KIND == 33) { SRT_CAL8(I33) } else if (KIND == 34) { SRT_CAL8(I34) } else if (KIND == 35) { SRT_CAL8(I35) }
+            else if (KIND == 36) { SRT_CAL8(I36) } else if (KIND == 39) { SRT_CAL8(I39) } else if (KIND == 40) { SRT_CAL8(I40) }
+            else if (KIND == 37) {
+                REP4(asm volatile(I37(0) I37(1) I37(2) I37(3) I37(4) I37(5) I37(6) I37(7)
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(k), "s"(sk), "s"(smask) : "s90", "s91");)
+            } else if (KIND == 38) {
+                REP4(asm volatile("s_mov_b64 vcc, %10\n" I28(0) I28(1) I28(2) I28(3) I28(4) I28(5) I28(6) I28(7)
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(k), "s"(sk), "s"(smask) : "vcc");)
+            }
+            else if (KIND >= 41 && KIND <= 46) {
+#define A(n) "v_add_f32 %" #n ", %" #n ", %8\n"
+#define SRT_CALX(BODY) REP4(asm volatile(BODY : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(k), "s"(sk), "s"(smask) : "vcc");)
+                if (KIND == 41) { SRT_CALX(I28(0) A(1) I28(2) A(3) I28(4) A(5) I28(6) A(7)) }                                 // stale VCC, every other instruction
+                else if (KIND == 42) { SRT_CALX(I36(0) I28(1) I28(2) A(3) I36(4) I28(5) I28(6) A(7)) }                        // v_cmp -> two VOP2 consumers
+                else if (KIND == 43) { SRT_CALX(I36(0) A(1) A(2) A(3) I28(4) A(5) A(6) A(7)) }                                // v_cmp ... three instructions ... consumer
+                else if (KIND == 44) { SRT_CALX("s_and_b64 vcc, vcc, %10\n" I28(0) I28(1) A(2) A(3) A(4) A(5) A(6) A(7)) }      // SALU-written VCC, two VOP2 consumers (the INNER visit's tail)
+                else if (KIND == 45) { SRT_CALX("s_and_b64 vcc, vcc, %10\n" I39(0) I39(1) A(2) A(3) A(4) A(5) A(6) A(7)) }      // the same with VOP3-encoded selects
+                else { SRT_CALX(I28(0) A(1) A(2) A(3) A(4) A(5) A(6) A(7)) }                                                  // one stale-VCC VOP2 select in eight
+            }
+            else if (KIND == 31) {
+                REP4(asm volatile("v_pk_add_f32 %0, %0, %8\n v_pk_add_f32 %1, %1, %8\n v_pk_add_f32 %2, %2, %8\n v_pk_add_f32 %3, %3, %8\n"
+                                  "v_pk_add_f32 %4, %4, %8\n v_pk_add_f32 %5, %5, %8\n v_pk_add_f32 %6, %6, %8\n v_pk_add_f32 %7, %7, %8\n"
+                                  : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7) : "v"(k2));)
+            }
         } else if (KIND == 9) {
             REP4(asm volatile("v_max3_f32 %0, %0, %8, %1\n v_max3_f32 %1, %1, %8, %2\n v_max3_f32 %2, %2, %8, %3\n v_max3_f32 %3, %3, %8, %4\n"
                               "v_max3_f32 %4, %4, %8, %5\n v_max3_f32 %5, %5, %8, %6\n v_max3_f32 %6, %6, %8, %7\n v_max3_f32 %7, %7, %8, %0\n"
@@ -210,6 +267,30 @@ hipError_t launch_calib(int kind, uint32_t n_blocks, uint32_t threads, uint32_t 
     case 20: return run_kind<20>(n_blocks, threads, iters, sink, cycles, table, n_records, st);
     case 21: return run_kind<21>(n_blocks, threads, iters, sink, cycles, table, n_records, st);
     case 22: return run_kind<22>(n_blocks, threads, iters, sink, cycles, table, n_records, st);
+    case 23: return run_kind<23>(n_blocks, threads, iters, sink, cycles, table, n_records, st);
+    case 24: return run_kind<24>(n_blocks, threads, iters, sink, cycles, table, n_records, st);
+    case 25: return run_kind<25>(n_blocks, threads, iters, sink, cycles, table, n_records, st);
+    case 26: return run_kind<26>(n_blocks, threads, iters, sink, cycles, table, n_records, st);
+    case 27: return run_kind<27>(n_blocks, threads, iters, sink, cycles, table, n_records, st);
+    case 28: return run_kind<28>(n_blocks, threads, iters, sink, cycles, table, n_records, st);
+    case 29: return run_kind<29>(n_blocks, threads, iters, sink, cycles, table, n_records, st);
+    case 30: return run_kind<30>(n_blocks, threads, iters, sink, cycles, table, n_records, st);
+    case 31: return run_kind<31>(n_blocks, threads, iters, sink, cycles, table, n_records, st);
+    case 32: return run_kind<32>(n_blocks, threads, iters, sink, cycles, table, n_records, st);
+    case 33: return run_kind<33>(n_blocks, threads, iters, sink, cycles, table, n_records, st);
+    case 34: return run_kind<34>(n_blocks, threads, iters, sink, cycles, table, n_records, st);
+    case 35: return run_kind<35>(n_blocks, threads, iters, sink, cycles, table, n_records, st);
+    case 36: return run_kind<36>(n_blocks, threads, iters, sink, cycles, table, n_records, st);
+    case 37: return run_kind<37>(n_blocks, threads, iters, sink, cycles, table, n_records, st);
+    case 38: return run_kind<38>(n_blocks, threads, iters, sink, cycles, table, n_records, st);
+    case 39: return run_kind<39>(n_blocks, threads, iters, sink, cycles, table, n_records, st);
+    case 40: return run_kind<40>(n_blocks, threads, iters, sink, cycles, table, n_records, st);
+    case 41: return run_kind<41>(n_blocks, threads, iters, sink, cycles, table, n_records, st);
+    case 42: return run_kind<42>(n_blocks, threads, iters, sink, cycles, table, n_records, st);
+    case 43: return run_kind<43>(n_blocks, threads, iters, sink, cycles, table, n_records, st);
+    case 44: return run_kind<44>(n_blocks, threads, iters, sink, cycles, table, n_records, st);
+    case 45: return run_kind<45>(n_blocks, threads, iters, sink, cycles, table, n_records, st);
+    case 46: return run_kind<46>(n_blocks, threads, iters, sink, cycles, table, n_records, st);
     default: return hipErrorInvalidValue;
     }
 }

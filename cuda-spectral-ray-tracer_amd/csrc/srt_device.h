@@ -507,6 +507,26 @@ __device__ __forceinline__ void trav_step_inner(Trav &tv, const NodeSrc &ns, V3 
 #define SRT_WAIT_Z
 #endif
 #endif
+// Encoding experiments of round 5 (profiles/r05/experiments/select_encodings.txt): eight back-to-back VOP2 selects on one VCC run at 23
+// cycles each in a microkernel (srt_calib kinds 28 / 38) against 4.3 for the VOP3 form with VCC as an explicit operand (39) -- but a VOP2
+// select between other vector instructions costs 2.5 (kinds 41-43), and in this block the two forms are within noise of each other
+// (330.2 vs 331.4 ms on cfg 3, no SDWA: 330.7).  The VOP2 forms stay.
+#ifndef SRT_ASM_SEL_E64
+#define SRT_ASM_SEL_E64 0
+#endif
+#if SRT_ASM_SEL_E64
+#define SRT_SEL_VCC "v_cndmask_b32_e64"
+#else
+#define SRT_SEL_VCC "v_cndmask_b32_e32"
+#endif
+#ifndef SRT_ASM_NO_SDWA
+#define SRT_ASM_NO_SDWA 0
+#endif
+#if SRT_ASM_NO_SDWA
+#define SRT_SEL_LREF "v_and_b32 v113, 0xffff, v112\n\t" "v_cndmask_b32_e64 %[node], v118, v113, vcc\n\t"
+#else
+#define SRT_SEL_LREF "v_cndmask_b32_sdwa %[node], v118, v112, vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n\t"
+#endif
 #define SRT_INNER_VISIT_ASM                                                                                              \
     "v_lshlrev_b32 v112, 4, %[node]\n\t"                                                                                 \
     "ds_write_b16 %[sp], %[top] offset:128\n\t"                                                                          \
@@ -554,12 +574,12 @@ __device__ __forceinline__ void trav_step_inner(Trav &tv, const NodeSrc &ns, V3 
     "v_lshrrev_b32 v117, 16, v112\n\t"                             /* rref */                                            \
     "s_or_b64 s[84:85], vcc, s[82:83]\n\t"                         /* any */                                             \
     "v_cndmask_b32_e64 v118, %[top], v117, s[82:83]\n\t"                                                                 \
-    "v_cndmask_b32_sdwa %[node], v118, v112, vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n\t" \
+    SRT_SEL_LREF                                                                                                         \
     "s_and_b64 vcc, vcc, s[82:83]\n\t"                             /* both */                                            \
     "v_cndmask_b32_e64 v118, %[ms], 0, s[84:85]\n\t"                                                                     \
     "v_cndmask_b32_e64 %[top], v116, %[top], s[84:85]\n\t"                                                               \
-    "v_cndmask_b32_e32 v118, v118, %[ps], vcc\n\t"                                                                       \
-    "v_cndmask_b32_e32 %[top], %[top], v117, vcc\n\t"                                                                    \
+    SRT_SEL_VCC " v118, v118, %[ps], vcc\n\t"                                                                            \
+    SRT_SEL_VCC " %[top], %[top], v117, vcc\n\t"                                                                         \
     "v_add_u32 %[sp], v118, %[sp]\n\t"
 #ifndef SRT_ASM_CMPX
 #define SRT_ASM_CMPX 1
@@ -742,8 +762,8 @@ __device__ __forceinline__ uint32_t inner_phase_asm(Trav &tv, const NodeSrc &ns,
     "s_and_b64 vcc, vcc, s[82:83]\n\t"                             /* both */                                            \
     "v_cndmask_b32_e64 v118, %[ms], 0, s[84:85]\n\t"                                                                     \
     "v_cndmask_b32_e64 %[top], v116, %[top], s[84:85]\n\t"                                                               \
-    "v_cndmask_b32_e32 v118, v118, %[ps], vcc\n\t"                                                                       \
-    "v_cndmask_b32_e32 %[top], %[top], v113, vcc\n\t"                                                                    \
+    SRT_SEL_VCC " v118, v118, %[ps], vcc\n\t"                                                                            \
+    SRT_SEL_VCC " %[top], %[top], v113, vcc\n\t"                                                                         \
     "v_add_u32 %[sp], v118, %[sp]\n\t"
 #define SRT_INNER_NEXT_MIXED_ASM                                                                                         \
     "v_cmpx_gt_u32 vcc, %[ninner], %[node]\n\t"                                                                          \
