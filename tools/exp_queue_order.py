@@ -15,7 +15,7 @@ r = srt.Renderer(0)
 scene = srt.Scene.builtin(sc, 0).build_bvh(1, 1984)
 r.upload_scene(scene); r.set_camera(scene.default_camera(W, H)); r.set_partition(0, 1)
 ms = []
-for _ in range(2):
+for _ in range(3):
     r.init_device_params(W, H, spp, 16, 1984)
     r.render_chunk(W, H); r.synchronize()
     ms.append(round(r.last_kernel_ms(), 1))
@@ -28,6 +28,11 @@ def opt(name, d):
 spp = int(opt("--spp", "256")); W, H = (int(x) for x in opt("--size", "3840x2160").split("x")); sc = int(opt("--scene", "101"))
 settings = [("default", {}), ("SRT_PROBE_SPP=0 (raster order)", {"SRT_PROBE_SPP": "0"}), ("SRT_ORDER_MAX_PCT=100", {"SRT_ORDER_MAX_PCT": "100"}),
             ("SRT_SPLIT_LOAD=0", {"SRT_SPLIT_LOAD": "0"}), ("default again", {})]
+if "--more" in sys.argv:      # the finer sweep (cfg 2: 3.5 pixels per lane, the tail is 19.5 % of the wave-slot time)
+    settings = [("default", {}), ("SRT_ORDER_MAX_PCT=50", {"SRT_ORDER_MAX_PCT": "50"}), ("SRT_ORDER_MAX_PCT=100", {"SRT_ORDER_MAX_PCT": "100"}),
+                ("SRT_ORDER_MAX_PCT=150", {"SRT_ORDER_MAX_PCT": "150"}), ("SRT_PROBE_SPP=4", {"SRT_PROBE_SPP": "4"}), ("SRT_PROBE_SPP=8", {"SRT_PROBE_SPP": "8"}),
+                ("SRT_PROBE_SPP=8 SRT_ORDER_MAX_PCT=100", {"SRT_PROBE_SPP": "8", "SRT_ORDER_MAX_PCT": "100"}), ("SRT_SPLIT_LOAD=0", {"SRT_SPLIT_LOAD": "0"}),
+                ("SRT_SPLIT_LOAD=100", {"SRT_SPLIT_LOAD": "100"}), ("SRT_SPLIT_LOAD=400", {"SRT_SPLIT_LOAD": "400"}), ("default again", {})]
 ref = None
 for name, extra in settings:
     env = dict(os.environ); env.update(extra)
