@@ -76,6 +76,12 @@ __device__ __forceinline__ bool near_zero(V3 v) {   // :93-98
 // utils/cuda_utility.cu:19-49.  Six 32-bit words per lane.
 // ------------------------------------------------------------------------------------------------
 struct Rng { uint32_t d, v0, v1, v2, v3, v4; };
+#ifndef SRT_XOR3
+#define SRT_XOR3 1               /* three of the four operands of the XORWOW step's xor in one v_bitop3_b32 (0: the compiler's three v_xor_b32) */
+#endif
+#ifndef SRT_ASM_RNG
+#define SRT_ASM_RNG 1            /* the two rejection loops (unit sphere, unit disk) as hand-scheduled assembly (0: the C++ loops) */
+#endif
 
 __device__ __forceinline__ void rng_seed(Rng &s, uint64_t seed) {
     uint32_t s0 = ((uint32_t)seed) ^ 0xaad26b49u;
@@ -92,7 +98,11 @@ __device__ __forceinline__ void rng_seed(Rng &s, uint64_t seed) {
 __device__ __forceinline__ uint32_t rng_next(Rng &s) {
     uint32_t t = s.v0 ^ (s.v0 >> 2);
     s.v0 = s.v1; s.v1 = s.v2; s.v2 = s.v3; s.v3 = s.v4;
+#if SRT_XOR3
+    s.v4 = __builtin_amdgcn_bitop3_b32(s.v4, s.v4 << 4, t, 0x96) ^ (t << 1);      // the same four-way xor, three of its operands in one v_bitop3_b32 (0x96 = a ^ b ^ c)
+#else
     s.v4 = (s.v4 ^ (s.v4 << 4)) ^ (t ^ (t << 1));
+#endif
     s.d += 362437u;
     return s.v4 + s.d;
 }
@@ -116,8 +126,84 @@ __device__ __forceinline__ float rng_pm1_from_bits(uint32_t r) {
     return __builtin_fmaf((float)r, 2.0f * 2.3283064e-10f, 2.3283064e-10f) + -1.0f;
 }
 __device__ __forceinline__ float rng_pm1(Rng &s) { return rng_pm1_from_bits(rng_next(s)); }
+// Three (two) consecutive rng_pm1 draws as one block of gfx950 assembly: the rejection loops of random_in_unit_sphere / random_in_unit_disk
+// run ~5.7 / ~2.9 times per shading pass for the whole wave, and the compiler rotates the five xorshift words through four (five) register
+// copies per iteration.  Here the state stays in its registers -- the words that only move take two (three) copies, the new ones are
+// computed in place -- and three operands of each step's four-way xor meet in one v_bitop3_b32.  Instruction for instruction rng_next +
+// rng_pm1_from_bits: t = x ^ (x >> 2); v' = v ^ (v << 4) ^ t ^ (t << 1); d += 362437; r = v' + d; fl(fl((float)r * 2^-31 + 2^-32) + -1).
+#define SRT_RNG_T(T, X)            "v_lshrrev_b32 " T ", 2, " X "\n\t" "v_xor_b32 " T ", " T ", " X "\n\t"
+#define SRT_RNG_STEP(OUT, PREV, T, A) "v_lshlrev_b32 " A ", 4, " PREV "\n\t" "v_bitop3_b32 " A ", " PREV ", " A ", " T " bitop3:0x96\n\t" \
+                                   "v_lshlrev_b32 " T ", 1, " T "\n\t" "v_xor_b32 " OUT ", " A ", " T "\n\t"
+#define SRT_RNG_PM1(R, N, K)       "v_add3_u32 " R ", %[d], " N ", " K "\n\t" "v_cvt_f32_u32 " R ", " R "\n\t" \
+                                   "v_fmamk_f32 " R ", " R ", 0x30000000, %[c32]\n\t" "v_add_f32 " R ", -1.0, " R "\n\t"
+// The whole rejection loop: `do { p = 3 (2) draws } while (!(|p|^2 < 1))`.  EXEC is saved once, the compare that accepts a lane's point takes the lane out
+// (v_cmpx), the loop runs while any lane is left; accepted lanes keep their point and their stream position because nothing writes them any more.
+// |p|^2 = (x*x + y*y) + z*z as length_squared (vec3.cuh:59-61) / (x*x + y*y) + 0*0 for the disk (vec3.cuh:240-246; the + 0 cannot change a sum of squares).
+// s[80:81] and VCC are scratch.
+__device__ __forceinline__ void rng_sphere_loop_asm(Rng &s, float &x, float &y, float &z, float &len2) {
+    uint32_t t2, t3, a;
+    float t1;
+    asm volatile(
+        "s_mov_b64 s[80:81], exec\n\t"
+        ".Lsrt_sphere_try%=:\n\t"
+        SRT_RNG_T("%[t1]", "%[v0]") SRT_RNG_T("%[t2]", "%[v1]") SRT_RNG_T("%[t3]", "%[v2]")
+        "v_mov_b32 %[v0], %[v3]\n\t"
+        SRT_RNG_STEP("%[v2]", "%[v4]", "%[t1]", "%[a]")                 /* n1 -> v2 (its old value lives on in t3) */
+        "v_mov_b32 %[v1], %[v4]\n\t"
+        SRT_RNG_PM1("%[x]", "%[v2]", "%[k1]")
+        SRT_RNG_STEP("%[v3]", "%[v2]", "%[t2]", "%[a]")                 /* n2 -> v3 */
+        SRT_RNG_PM1("%[y]", "%[v3]", "%[k2]")
+        SRT_RNG_STEP("%[v4]", "%[v3]", "%[t3]", "%[a]")                 /* n3 -> v4 */
+        SRT_RNG_PM1("%[z]", "%[v4]", "%[k3]")
+        "v_add_u32 %[d], %[k3], %[d]\n\t"
+        "v_mul_f32 %[t1], %[x], %[x]\n\t"
+        "v_mul_f32 %[t2], %[y], %[y]\n\t"
+        "v_mul_f32 %[t3], %[z], %[z]\n\t"
+        "v_add_f32 %[t1], %[t1], %[t2]\n\t"
+        "v_add_f32 %[t1], %[t1], %[t3]\n\t"
+        "v_cmpx_ngt_f32 vcc, 1.0, %[t1]\n\t"                          /* stay while !(|p|^2 < 1) */
+        "s_cbranch_execnz .Lsrt_sphere_try%=\n\t"
+        "s_mov_b64 exec, s[80:81]\n\t"
+        : [v0] "+v"(s.v0), [v1] "+v"(s.v1), [v2] "+v"(s.v2), [v3] "+v"(s.v3), [v4] "+v"(s.v4), [d] "+v"(s.d),
+          [x] "=&v"(x), [y] "=&v"(y), [z] "=&v"(z), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [a] "=&v"(a)
+        : [k1] "s"(362437u), [k2] "s"(2u * 362437u), [k3] "s"(3u * 362437u), [c32] "v"(2.3283064e-10f)
+        : "s80", "s81", "vcc");
+    len2 = t1;      // (x*x + y*y) + z*z of the accepted point: what unit_vector takes the root of
+}
+__device__ __forceinline__ void rng_disk_loop_asm(Rng &s, float &x, float &y) {
+    uint32_t t1, t2, a;
+    asm volatile(
+        "s_mov_b64 s[80:81], exec\n\t"
+        ".Lsrt_disk_try%=:\n\t"
+        SRT_RNG_T("%[t1]", "%[v0]") SRT_RNG_T("%[t2]", "%[v1]")
+        "v_mov_b32 %[v0], %[v2]\n\t"
+        "v_mov_b32 %[v1], %[v3]\n\t"
+        SRT_RNG_STEP("%[v3]", "%[v4]", "%[t1]", "%[a]")                 /* n1 -> v3 */
+        "v_mov_b32 %[v2], %[v4]\n\t"
+        SRT_RNG_PM1("%[x]", "%[v3]", "%[k1]")
+        SRT_RNG_STEP("%[v4]", "%[v3]", "%[t2]", "%[a]")                 /* n2 -> v4 */
+        SRT_RNG_PM1("%[y]", "%[v4]", "%[k2]")
+        "v_add_u32 %[d], %[k2], %[d]\n\t"
+        "v_mul_f32 %[t1], %[x], %[x]\n\t"
+        "v_mul_f32 %[t2], %[y], %[y]\n\t"
+        "v_add_f32 %[t1], %[t1], %[t2]\n\t"
+        "v_cmpx_ngt_f32 vcc, 1.0, %[t1]\n\t"
+        "s_cbranch_execnz .Lsrt_disk_try%=\n\t"
+        "s_mov_b64 exec, s[80:81]\n\t"
+        : [v0] "+v"(s.v0), [v1] "+v"(s.v1), [v2] "+v"(s.v2), [v3] "+v"(s.v3), [v4] "+v"(s.v4), [d] "+v"(s.d),
+          [x] "=&v"(x), [y] "=&v"(y), [t1] "=&v"(t1), [t2] "=&v"(t2), [a] "=&v"(a)
+        : [k1] "s"(362437u), [k2] "s"(2u * 362437u), [c32] "v"(2.3283064e-10f)
+        : "s80", "s81", "vcc");
+}
 // random_in_unit_sphere (math/vec3.cuh:210-218); draws x, y, z in that order (DESIGN.md D1 / SURVEY Q19)
 __device__ __forceinline__ V3 random_in_unit_sphere(Rng &s) {
+#if SRT_ASM_RNG
+    {
+        float x, y, z, len2;
+        rng_sphere_loop_asm(s, x, y, z, len2);
+        return mk(x, y, z);
+    }
+#endif
     for (;;) {
         float x = rng_pm1(s);
         float y = rng_pm1(s);
@@ -125,6 +211,19 @@ __device__ __forceinline__ V3 random_in_unit_sphere(Rng &s) {
         V3 p = mk(x, y, z);
         if (length_squared(p) < 1.0f) return p;
     }
+}
+
+// random_unit_vector = unit_vector(random_in_unit_sphere()) (vec3.cuh:221-227): the accepted point's |p|^2 is the one the loop's
+// test computed (same three products, same two sums), so the assembly loop hands it over instead of the caller squaring again
+__device__ __forceinline__ V3 random_unit_vector(Rng &s) {
+#if SRT_ASM_RNG
+    float x, y, z, len2;
+    rng_sphere_loop_asm(s, x, y, z, len2);
+    const float k = 1.0f / sqrtf(len2);
+    return k * mk(x, y, z);
+#else
+    return unit_vector(random_in_unit_sphere(s));
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -318,7 +318,7 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
                         }
                     } else {
                         // METALLIC (:64-71) and LAMBERTIAN/default (:88-92) both start with random_unit_vector
-                        const V3 ruv = unit_vector(random_in_unit_sphere(rs));             // vec3.cuh:221-227
+                        const V3 ruv = random_unit_vector(rs);                            // vec3.cuh:221-227
                         if (mtype == 1u) {
                             V3 reflected = reflect(unit_in, n);                            // reflection_scatter, :22-37
                             scatter_direction = reflected + fuzz * ruv;
@@ -553,11 +553,15 @@ __global__ __launch_bounds__(1024) void render_kernel(const RenderParams P) {
                 V3 origin = cam_center;
                 if (!(U->defocus_angle <= 0.0f)) {                          // defocus_disk_sample, :42-47
                     float dx, dy;
+#if SRT_ASM_RNG
+                    rng_disk_loop_asm(rs, dx, dy);                         // random_in_unit_disk, vec3.cuh:240-246 (srt_device.h)
+#else
                     for (;;) {                                             // random_in_unit_disk, vec3.cuh:240-246
                         dx = rng_pm1(rs);
                         dy = rng_pm1(rs);
                         if ((dx * dx + dy * dy) + 0.0f * 0.0f < 1.0f) break;
                     }
+#endif
                     origin = (cam_center + dx * mk(U->disk_u[0], U->disk_u[1], U->disk_u[2])) +
                              dy * mk(U->disk_v[0], U->disk_v[1], U->disk_v[2]);
                 }
