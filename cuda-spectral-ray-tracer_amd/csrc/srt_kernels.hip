@@ -955,6 +955,19 @@ __global__ void op_sweep_kernel(int which, const float *a, const float *b, uint3
     // the product's Sellmeier arithmetic with coefficients B = b[0..2], C = b[3..5] at wavelength a[k]: compared with the reference's
     // own sellmeier_index compiled from its source (tests/test_ref_tables.py)
     case 22: r = n >= 6u ? sellmeier_index(b[0], b[1], b[2], b[3], b[4], b[5], x) : 0.f; break;
+    // the hand-scheduled rejection loops (srt_device.h) from the stream curand_init(seed = bits of a[k]) would start: the accepted point, its |p|^2
+    // and a fold of the stream position they leave behind -- every lane of a wave needs another number of tries, so the v_cmpx bookkeeping of the
+    // loops runs fully divergent here.  Checked against a host restatement of XORWOW + the C++ loops (tests/test_gpu_parity.py).
+    case 23: case 24: case 25: case 26: case 27: {
+        Rng s; rng_seed(s, (uint64_t)__float_as_uint(x));
+        float px, py, pz, l2; rng_sphere_loop_asm(s, px, py, pz, l2);
+        r = which == 23 ? px : which == 24 ? py : which == 25 ? pz : which == 26 ? l2 : __uint_as_float(s.d ^ (s.v0 * 3u) ^ (s.v1 * 5u) ^ (s.v2 * 7u) ^ (s.v3 * 11u) ^ (s.v4 * 13u));
+    } break;
+    case 28: case 29: case 30: {
+        Rng s; rng_seed(s, (uint64_t)__float_as_uint(x));
+        float px, py; rng_disk_loop_asm(s, px, py);
+        r = which == 28 ? px : which == 29 ? py : __uint_as_float(s.d ^ (s.v0 * 3u) ^ (s.v1 * 5u) ^ (s.v2 * 7u) ^ (s.v3 * 11u) ^ (s.v4 * 13u));
+    } break;
     default: r = 0.f;
     }
     out[k] = r;

@@ -76,6 +76,58 @@ def test_primitive_op_sweep(gpu, orc):
     assert _same(gpu.op_sweep(7, small, b), np.trunc(small).astype(np.int32).astype(np.float32))
 
 
+def _xorwow_host(seeds):
+    """cuRAND XORWOW (curand_init(seed, 0, 0) + curand()) on arrays of seeds: returns (state dict, next()) -- numpy restatement of srt_device.h's
+    rng_seed / rng_next (the oracle restates the same published definition in C)."""
+    u = np.uint32
+    s0 = seeds.astype(u) ^ u(0xaad26b49); s1 = np.zeros_like(s0) ^ u(0xf7dcefdd)
+    t0 = u(1099087573) * s0; t1 = u(2591861531) * s1
+    st = {"d": u(6615241) + t1 + t0, "v": [u(123456789) + t0, u(362436069) ^ t0, u(521288629) + t1, u(88675123) ^ t1, u(5783321) + t0]}
+    def nxt(mask):
+        v = st["v"]
+        t = v[0] ^ (v[0] >> u(2))
+        n4 = (v[4] ^ (v[4] << u(4))) ^ (t ^ (t << u(1)))
+        new = [v[1], v[2], v[3], v[4], n4]
+        for k in range(5): v[k] = np.where(mask, new[k], v[k])
+        st["d"] = np.where(mask, st["d"] + u(362437), st["d"])
+        return v[4] + st["d"]
+    return st, nxt
+
+
+def test_rejection_loops_in_assembly_match_host_restatement(gpu):
+    """rng_sphere_loop_asm / rng_disk_loop_asm (the v33 kernels' hand-scheduled random_in_unit_sphere / random_in_unit_disk): accepted point, |p|^2 and the
+    stream position left behind, for 2^16 streams whose lanes need different numbers of tries, against XORWOW + the reference's loops in numpy
+    (math/vec3.cuh:210-218,240-246; draws x, y, z in that order, D1)."""
+    rng = np.random.default_rng(33)
+    n = 1 << 16
+    seeds = np.concatenate([np.arange(1984, 1984 + n // 2, dtype=np.uint32), rng.integers(0, 1 << 32, n // 2, dtype=np.uint64).astype(np.uint32)])
+    a = seeds.view(np.float32); b = np.zeros(n, np.float32)
+    f = np.float32
+    def pm1(r):
+        return (r.astype(f) * f(2.0 * 2.3283064e-10) + f(2.3283064e-10)) + f(-1.0)      # (exact product: one rounding at the first add, like the device's fma)
+    fold = lambda st: st["d"] ^ (st["v"][0] * np.uint32(3)) ^ (st["v"][1] * np.uint32(5)) ^ (st["v"][2] * np.uint32(7)) ^ (st["v"][3] * np.uint32(11)) ^ (st["v"][4] * np.uint32(13))
+    with np.errstate(over="ignore"):
+        for draws, kinds in ((3, (23, 24, 25, 26, 27)), (2, (28, 29, None, None, 30))):
+            st, nxt = _xorwow_host(seeds)
+            todo = np.ones(n, bool)
+            p = [np.zeros(n, f) for _ in range(3)]
+            l2 = np.zeros(n, f)
+            tries = 0
+            while todo.any():
+                c = [pm1(nxt(todo)) for _ in range(draws)] + [np.zeros(n, f)] * (3 - draws)
+                q = (c[0] * c[0] + c[1] * c[1]) + c[2] * c[2]
+                for k in range(3): p[k] = np.where(todo, c[k], p[k])
+                l2 = np.where(todo, q, l2)
+                todo = todo & ~(q < f(1.0))
+                tries += 1
+            assert tries > 6      # (some lane needed many tries: the loops ran divergent)
+            want = [p[0], p[1], p[2], l2, fold(st).view(np.float32)]
+            for kind, w in zip(kinds, want):
+                if kind is None: continue
+                got = gpu.op_sweep(kind, a, b)
+                assert np.array_equal(bits(got), bits(w)), "kind %d differs on %d streams" % (kind, int(np.sum(bits(got) != bits(w))))
+
+
 def test_powf_matches_oracle_and_libm(gpu, orc):
     rng = np.random.default_rng(11)
     n = 1 << 18
