@@ -968,6 +968,16 @@ __global__ void op_sweep_kernel(int which, const float *a, const float *b, uint3
         float px, py; rng_disk_loop_asm(s, px, py);
         r = which == 28 ? px : which == 29 ? py : __uint_as_float(s.d ^ (s.v0 * 3u) ^ (s.v1 * 5u) ^ (s.v2 * 7u) ^ (s.v3 * 11u) ^ (s.v4 * 13u));
     } break;
+    // rng_next alone (the v_bitop3 form every other draw of the render kernels goes through), (bits of b[k]) steps from the stream
+    // curand_init(seed = bits of a[k]) would start: xor of the outputs / weighted wrapping sum / fold of the words afterwards.  Held against
+    // rocRAND's xorwow_engine::next() run from the same words (oracle/rocrand_xorwow_pin.hip, tests/test_rocrand_xorwow_pin.py).
+    case 31: case 32: case 33: {
+        Rng s; rng_seed(s, (uint64_t)__float_as_uint(x));
+        const uint32_t steps = __float_as_uint(y);
+        uint32_t xo = 0u, sm = 0u;
+        for (uint32_t i = 0; i < steps; i++) { const uint32_t v = rng_next(s); xo ^= v; sm += v * (2u * i + 1u); }
+        r = __uint_as_float(which == 31 ? xo : which == 32 ? sm : s.d ^ (s.v0 * 3u) ^ (s.v1 * 5u) ^ (s.v2 * 7u) ^ (s.v3 * 11u) ^ (s.v4 * 13u));
+    } break;
     default: r = 0.f;
     }
     out[k] = r;
