@@ -31,6 +31,9 @@
  *   - Third-party arithmetic restated from published definitions, unpinned upstream:
  *       cuRAND XORWOW (curand_init / curand / curand_uniform; CUDA toolkit, version unpinned by
  *       the reference's CMakeLists.txt:2) and CUDA's powf (replaced by srt_powf, see below).
+ *       Of XORWOW, the recurrence (orc_rng_next) is held against rocRAND's xorwow_engine::next() -- an independent
+ *       implementation that ships with this image's ROCm -- by rocrand_xorwow_pin.hip / tests/test_rocrand_xorwow_pin.py;
+ *       curand_init's seed scramble and curand_uniform's float mapping differ from rocRAND's by design and stay restated only.
  *
  * Deliberate, documented deviations from the reference text (all in DESIGN.md):
  *   D1  vec3::random / random_in_unit_disk draw x, then y, then z (reference leaves the order
