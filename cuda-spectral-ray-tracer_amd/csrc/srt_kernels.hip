@@ -970,7 +970,7 @@ __global__ void op_sweep_kernel(int which, const float *a, const float *b, uint3
     } break;
     // rng_next alone (the v_bitop3 form every other draw of the render kernels goes through), (bits of b[k]) steps from the stream
     // curand_init(seed = bits of a[k]) would start: xor of the outputs / weighted wrapping sum / fold of the words afterwards.  Held against
-    // rocRAND's xorwow_engine::next() run from the same words (oracle/rocrand_xorwow_pin.hip, tests/test_rocrand_xorwow_pin.py).
+    // rocRAND's xorwow_engine::next() run from the same words (tests/test_rocrand_xorwow_pin.py).
     case 31: case 32: case 33: {
         Rng s; rng_seed(s, (uint64_t)__float_as_uint(x));
         const uint32_t steps = __float_as_uint(y);
